@@ -1,0 +1,111 @@
+"""Golden-vector case list shared by the generator (make_golden.py, runs the
+imported reference in the build container) and by the tests (oracle on CPU,
+HIP path on the GPU).  A case = class kind + ctor kwargs + input shape + seed.
+Sizes follow SURVEY.md section 8(c) G1..G8; own data, no reference content."""
+from __future__ import annotations
+
+FFNO2D_CFG3 = dict(in_channels=1, out_channels=1, width=64, n_layers=4, n_modes=20, factor=4,
+                   ff_weight_norm=True, n_ff_layers=3, layer_norm=True, dropout=0.0)
+FFNO1D_YAML = dict(in_channels=1, out_channels=1, width=128, n_layers=4, n_modes=64, factor=4,
+                   ff_weight_norm=True, n_ff_layers=3, layer_norm=True, dropout=0.0,
+                   mode="full", activation="gelu", use_grid=True)
+
+CASES = [
+    # ---- G1 SpectralConv1d ------------------------------------------------
+    dict(name="sc1d_cfg1", kind="SpectralConv1d", ctor=dict(in_channels=64, out_channels=64, modes1=16),
+         x=(16, 64, 1024), seed=101),
+    dict(name="sc1d_small", kind="SpectralConv1d", ctor=dict(in_channels=8, out_channels=6, modes1=5),
+         x=(3, 8, 32), seed=102),
+    dict(name="sc1d_odd", kind="SpectralConv1d", ctor=dict(in_channels=4, out_channels=4, modes1=7),
+         x=(2, 4, 33), seed=103),
+    dict(name="sc1d_nyquist", kind="SpectralConv1d", ctor=dict(in_channels=4, out_channels=5, modes1=9),
+         x=(2, 4, 16), seed=104),
+    # ---- G2 SpectralConv2d ------------------------------------------------
+    dict(name="sc2d_64", kind="SpectralConv2d", ctor=dict(in_channels=32, out_channels=32, modes1=12, modes2=12),
+         x=(2, 32, 64, 64), seed=201),
+    dict(name="sc2d_256", kind="SpectralConv2d", ctor=dict(in_channels=32, out_channels=32, modes1=12, modes2=12),
+         x=(1, 32, 256, 256), seed=202),
+    dict(name="sc2d_overlap", kind="SpectralConv2d", ctor=dict(in_channels=4, out_channels=4, modes1=12, modes2=8),
+         x=(2, 4, 16, 16), seed=203),
+    dict(name="sc2d_nyquist_rect", kind="SpectralConv2d", ctor=dict(in_channels=3, out_channels=5, modes1=4, modes2=11),
+         x=(2, 3, 12, 20), seed=204),
+    # ---- G3 FSpectralConv1d -----------------------------------------------
+    dict(name="fs1d_cfg2", kind="FSpectralConv1d",
+         ctor=dict(d_model=128, modes=64, factor=4, n_ff_layers=3, layer_norm=True, activation="gelu"),
+         x=(4, 512, 128), seed=301),
+    dict(name="fs1d_clamp", kind="FSpectralConv1d",
+         ctor=dict(d_model=16, modes=64, factor=2, n_ff_layers=2, layer_norm=True),
+         x=(2, 32, 16), seed=302),
+    dict(name="fs1d_lowpass", kind="FSpectralConv1d",
+         ctor=dict(d_model=16, modes=6, factor=2, n_ff_layers=2, layer_norm=False, mode="low-pass", activation="relu"),
+         x=(2, 40, 16), seed=303),
+    dict(name="fs1d_nofourier", kind="FSpectralConv1d",
+         ctor=dict(d_model=16, modes=6, factor=2, n_ff_layers=3, layer_norm=True, mode="no-fourier"),
+         x=(2, 40, 16), seed=304),
+    dict(name="fs1d_backward_norm", kind="FSpectralConv1d",
+         ctor=dict(d_model=8, modes=5, factor=2, n_ff_layers=2, layer_norm=True, fft_norm="backward"),
+         x=(3, 24, 8), seed=305),
+    # ---- G4 FSpectralConv2d -----------------------------------------------
+    dict(name="fs2d_r32", kind="FSpectralConv2d",
+         ctor=dict(d_model=64, modes=20, factor=4, n_ff_layers=3, layer_norm=True), x=(1, 32, 32, 64), seed=401),
+    dict(name="fs2d_r64", kind="FSpectralConv2d",
+         ctor=dict(d_model=64, modes=20, factor=4, n_ff_layers=3, layer_norm=True), x=(1, 64, 64, 64), seed=402),
+    dict(name="fs2d_r128", kind="FSpectralConv2d",
+         ctor=dict(d_model=64, modes=20, factor=4, n_ff_layers=3, layer_norm=True), x=(1, 128, 128, 64), seed=403),
+    dict(name="fs2d_r256", kind="FSpectralConv2d",
+         ctor=dict(d_model=64, modes=20, factor=4, n_ff_layers=3, layer_norm=True), x=(1, 256, 256, 64), seed=404),
+    dict(name="fs2d_rect_small", kind="FSpectralConv2d",
+         ctor=dict(d_model=8, modes=5, factor=2, n_ff_layers=2, layer_norm=True), x=(2, 24, 40, 8), seed=405),
+    dict(name="fs2d_fork", kind="FSpectralConv2d",
+         ctor=dict(d_model=8, modes=4, factor=2, n_ff_layers=2, layer_norm=False, use_fork=True), x=(2, 16, 16, 8), seed=406),
+    dict(name="fs2d_lowpass", kind="FSpectralConv2d",
+         ctor=dict(d_model=8, modes=4, factor=2, n_ff_layers=2, layer_norm=True, mode="low-pass"), x=(2, 16, 20, 8), seed=407),
+    # ---- FeedForward / WNLinear --------------------------------------------
+    dict(name="ff_cfg3", kind="FeedForward", ctor=dict(dim=64, factor=4, n_layers=3, layer_norm=True),
+         x=(2, 16, 16, 64), seed=451),
+    dict(name="ff_2layer_noln", kind="FeedForward", ctor=dict(dim=32, factor=2, n_layers=2, layer_norm=False),
+         x=(3, 50, 32), seed=452),
+    dict(name="wnlinear_wn", kind="WNLinear", ctor=dict(in_features=3, out_features=64, wnorm=True),
+         x=(2, 8, 8, 3), seed=461),
+    dict(name="wnlinear_plain", kind="WNLinear", ctor=dict(in_features=64, out_features=1, wnorm=False),
+         x=(2, 8, 8, 64), seed=462),
+    # ---- G5 whole models ---------------------------------------------------
+    dict(name="fno1d_cfg1", kind="FNO1d", ctor=dict(in_channels=1, out_channels=1, modes=16, width=64),
+         x=(16, 1, 1024), seed=501),
+    dict(name="ffno1d_cfg2", kind="FFNO1D", ctor=FFNO1D_YAML, x=(4, 1, 512), seed=502),
+    dict(name="ffno1d_small_grid", kind="FFNO1D",
+         ctor=dict(in_channels=2, out_channels=1, width=16, n_layers=2, n_modes=6, factor=2, ff_weight_norm=False,
+                   n_ff_layers=2, layer_norm=True, dropout=0.0, grid=[i / 39.0 for i in range(40)]),
+         x=(3, 2, 40), seed=503),
+    dict(name="ffno2d_cfg3_64", kind="FFNO2D", ctor=FFNO2D_CFG3, x=(2, 1, 64, 64), seed=511),
+    dict(name="ffno2d_cfg3_128", kind="FFNO2D", ctor=FFNO2D_CFG3, x=(1, 1, 128, 128), seed=512),
+    dict(name="ffno2d_cfg3_256", kind="FFNO2D", ctor=FFNO2D_CFG3, x=(1, 1, 256, 256), seed=513),
+    dict(name="ffno2d_small_nowm", kind="FFNO2D",
+         ctor=dict(in_channels=2, out_channels=3, width=16, n_layers=2, n_modes=5, factor=2, ff_weight_norm=False,
+                   n_ff_layers=2, layer_norm=False, dropout=0.0, use_grid=False),
+         x=(2, 2, 20, 24), seed=514),
+    dict(name="fno2d_256", kind="FNO2d", ctor=dict(in_channels=1, out_channels=1, modes1=12, modes2=12, width=32),
+         x=(1, 1, 256, 256), seed=521),
+    dict(name="fno2d_512", kind="FNO2d", ctor=dict(in_channels=1, out_channels=1, modes1=12, modes2=12, width=32),
+         x=(1, 1, 512, 512), seed=522, grads=False),
+    dict(name="fno2d_small", kind="FNO2d", ctor=dict(in_channels=2, out_channels=2, modes1=3, modes2=4, width=8, n_blocks=2),
+         x=(2, 2, 16, 20), seed=523),
+    # ---- G6 loss -----------------------------------------------------------
+    dict(name="loss_mean", kind="RelativeL2Loss", ctor=dict(size_average=True, reduction=True), x=(4, 1, 64, 64), seed=601),
+    dict(name="loss_sum", kind="RelativeL2Loss", ctor=dict(size_average=False, reduction=True), x=(4, 1, 64, 64), seed=602),
+    dict(name="loss_none_zero_target", kind="RelativeL2Loss", ctor=dict(size_average=True, reduction=False),
+         x=(5, 2, 33), seed=603, zero_target_row=2),
+    # ---- G7 one AdamW step -------------------------------------------------
+    dict(name="adamw_ffno2d_64", kind="AdamWStep", model="FFNO2D", ctor=FFNO2D_CFG3, x=(2, 1, 64, 64), seed=701,
+         lr=1e-3),
+    dict(name="adamw_fno2d_small", kind="AdamWStep", model="FNO2d",
+         ctor=dict(in_channels=1, out_channels=1, modes1=4, modes2=4, width=8), x=(2, 1, 32, 32), seed=702, lr=1e-3),
+    # ---- G8 1-D rollout ----------------------------------------------------
+    dict(name="rollout_ffno1d", kind="Rollout1d",
+         ctor=dict(in_channels=1, out_channels=1, width=32, n_layers=2, n_modes=12, factor=2, ff_weight_norm=True,
+                   n_ff_layers=2, layer_norm=True, dropout=0.0, activation="gelu"),
+         x=(3, 64), seed=801, steps=4, mean=0.3, std=1.7),
+]
+
+BY_NAME = {c["name"]: c for c in CASES}
+MODEL_KINDS = ("FNO1d", "FNO2d", "FFNO1D", "FFNO2D")

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the IMPORTED reference (build container only).
+
+Run:  python tests/golden/make_golden.py [case-name ...]
+
+The reference tree (/root/reference, read-only) is put on sys.path with an
+in-process stub for its unused ``import h5py``; nothing
+from it is copied: the fixtures hold only the parameter layout (names, shapes,
+dtypes), digests of outputs / gradients (full tensors when small, 8192 sampled
+scalars + norm + sum when large) for the numpy-seeded inputs and weights of
+``synth.py``.  The GPU box never sees the reference; it reads these files.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def _reference_namespace():
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    sys.path.insert(0, REF)
+    warnings.filterwarnings("ignore")
+    from models.spectral_convolution import (SpectralConv1d, SpectralConv2d, FSpectralConv1d,
+                                             FSpectralConv2d)
+    from models.custom_layer import FeedForward, WNLinear
+    from models.fno import FNO1d, FNO2d
+    from models.ffno import FFNO1D, FFNO2D
+    from utils.loss import RelativeL2Loss
+    sys.path.remove(REF)
+    # drop the reference's top-level package names so they cannot shadow ours
+    ns = types.SimpleNamespace(**{k: v for k, v in locals().items() if k[0].isupper()})
+    for name in [m for m in sys.modules if m.split(".")[0] in ("models", "utils")]:
+        del sys.modules[name]
+    return ns
+
+
+def main(argv):
+    ns = _reference_namespace()
+    sys.path.insert(0, REPO)
+    import torch
+    from tests.golden import synth
+    from tests.golden.cases import CASES
+    from tests.golden.runner import ModuleBackend, run_case
+
+    torch.set_num_threads(8)
+    backend = ModuleBackend(ns, "cpu")
+    want = set(argv)
+    for case in CASES:
+        if want and case["name"] not in want:
+            continue
+        t0 = time.time()
+        spec = {} if case["kind"] == "RelativeL2Loss" else backend.spec(case)
+        sd = synth.fill_state_dict(spec, case["seed"])
+        res = run_case(case, backend, sd)
+        blob = {"meta": np.array(json.dumps({"case": case, "spec": spec,
+                                             "torch": torch.__version__}))}
+        for name, t in res.items():
+            for k, v in synth.digest(t).items():
+                blob[f"{name}|{k}"] = v
+        path = os.path.join(HERE, case["name"] + ".npz")
+        np.savez_compressed(path, **blob)
+        print(f"{case['name']:28s} {len(res):3d} tensors  {os.path.getsize(path) / 1024:8.1f} KiB"
+              f"  {time.time() - t0:6.1f}s", flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
