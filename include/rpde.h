@@ -1,0 +1,226 @@
+/*
+ * rpde.h -- C ABI of librpde_hip.so: the MI355X (gfx950) implementation of the
+ * spectral-convolution hot path of RohanVKashyap/resolution-pde.
+ *
+ * Boundary rules:
+ *   - plain C, raw DEVICE pointers + sizes + a hipStream_t (passed as void*);
+ *     no torch types, no exceptions; every entry point returns 0 on success or
+ *     a negative rpde_status; rpde_last_error() gives the thread-local message.
+ *   - the caller (PyTorch) owns every tensor, including workspaces and the
+ *     tensors saved for backward; the library owns only DFT plans (small
+ *     device tables) inside opaque handles / an internal mutex-guarded cache.
+ *   - all tensors are fp32 and contiguous in the stated layout; complex64
+ *     parameters are passed as their (re,im)-interleaved float storage.
+ *   - entry points are re-entrant per device and asynchronous on `stream`.
+ *
+ * Each entry point cites the reference code it replaces (paths are relative to
+ * the reference repository root).
+ */
+#ifndef RPDE_H
+#define RPDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  RPDE_OK = 0,
+  RPDE_ERR_ARG = -1,        /* bad shape / null pointer / unsupported option    */
+  RPDE_ERR_HIP = -2,        /* a HIP runtime call or launch failed              */
+  RPDE_ERR_WORKSPACE = -3,  /* workspace smaller than the *_ws_bytes() answer   */
+  RPDE_ERR_MODES = -4       /* modes exceed the spectrum (SpectralConv* quirk Q5) */
+} rpde_status;
+
+/* fft_norm as torch.fft spells it */
+enum { RPDE_NORM_BACKWARD = 0, RPDE_NORM_ORTHO = 1, RPDE_NORM_FORWARD = 2 };
+/* FSpectralConv* `mode` (models/spectral_convolution.py:187-196, 273-281) */
+enum { RPDE_MODE_FULL = 0, RPDE_MODE_LOWPASS = 1 };
+/* activations (models/spectral_convolution.py:104-106, fno_blocks.py:33,71) */
+enum { RPDE_ACT_IDENTITY = 0, RPDE_ACT_GELU = 1, RPDE_ACT_RELU = 2 };
+
+const char* rpde_last_error(void);
+int rpde_version(void);
+
+/* ---- DFT plans ---------------------------------------------------------
+ * Truncated real-DFT tables for (n, modes, norm): the R2C transform restricted
+ * to bins [0,modes) and the C2R transform of a spectrum that is zero beyond
+ * them (Im(DC)/Im(Nyquist) ignored, as torch.fft.irfft does).  Replaces the
+ * torch.fft.rfft / irfft calls at models/spectral_convolution.py:41,54,165,198,
+ * 265,284,289,308.  The op entry points below look plans up in an internal
+ * cache; create/destroy are exported for callers that want to pre-plan
+ * (multi-resolution batches, SURVEY hard part 6). */
+typedef struct rpde_plan rpde_plan;
+int rpde_plan_create(rpde_plan** plan, int n, int modes, int norm, void* stream);
+int rpde_plan_destroy(rpde_plan* plan);
+/* copies of the float tables for tests: analysis [2*kp, ldn], synthesis [n, 2*kp] */
+int rpde_plan_info(const rpde_plan* plan, int* n, int* modes, int* kp, int* ldn);
+int rpde_plan_tables(const rpde_plan* plan, float* analysis_host, float* synthesis_host);
+
+/* ---- generic strided batched GEMM (fp32 MFMA) -----------------------------
+ * C[z][m,n] (+)= alpha * sum_k A[z][m,k] * B[z][k,n]  with fused prologue /
+ * epilogue.  Everything heavy below is expressed through it; exported so the
+ * parity tests and bench.py can time the kernel itself. */
+typedef struct {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int a_kmajor;            /* 1: A[m*lda+k] (k contiguous)   0: A[k*lda+m]          */
+  int b_kmajor;            /* 1: B^T stored, B[n*ldb+k]      0: B[k*ldb+n]          */
+  int64_t lda, ldb, ldc;
+  int batch, zdiv;         /* z in [0,batch): z1 = z / zdiv, z2 = z % zdiv          */
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+  int ksplit;              /* >1: split K, partial s goes to C + s*sCk (no epilogue) */
+  int64_t sCk;
+  float alpha;
+  int accumulate;          /* C += result                                           */
+  const float* bias; int bias_mode;   /* 0 none, 1 bias[n], 2 bias[m]                */
+  /* activation applied to an operand while it is staged (h = act(drop(z))) */
+  int act_a, act_b;        /* RPDE_ACT_*                                            */
+  /* epilogue: C = acc * act'(drop(aux)) * dropscale   (backward through act)      */
+  int epi_dact;            /* RPDE_ACT_* or 0                                       */
+  const float* aux; int64_t ldaux;
+  /* dropout shared by prologue / epilogue: element id = point*drop_ld + feature    */
+  float drop_p; uint64_t drop_seed; int64_t drop_ld;
+  int write_act;           /* epilogue applies act (RPDE_ACT_*) to the stored value */
+} rpde_gemm_desc;
+int rpde_gemm_f32(const rpde_gemm_desc* d, void* stream);
+
+/* ---- FSpectralConv1d.forward_fourier  (models/spectral_convolution.py:158-204)
+ * x,out [B,n,C] channels-last; w [C,C,K,2]; keff=min(K,n/2+1) is clamped here
+ * (quirk Q5).  spec_in [B, 2*kp, C] (kp = keff rounded up to 4) receives the
+ * truncated input spectrum and must be kept for the backward call. */
+size_t rpde_fspectral1d_ws_bytes(int B, int n, int C, int K);
+size_t rpde_fspectral1d_spec_elems(int B, int n, int C, int K);
+int rpde_fspectral1d_fwd(const float* x, const float* w, float* out, float* spec_in,
+                         int B, int n, int C, int K, int mode, int norm,
+                         void* ws, size_t ws_bytes, void* stream);
+int rpde_fspectral1d_bwd(const float* grad_out, const float* spec_in, const float* w,
+                         float* grad_x, float* grad_w,
+                         int B, int n, int C, int K, int mode, int norm,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- FSpectralConv2d.forward_fourier  (models/spectral_convolution.py:256-318)
+ * x,out [B,M,N,C]; w_y,w_x [C,C,K,2]; norm 'ortho' (hard-coded in the
+ * reference, quirk Q4).  spec_y [B*M, 2*kpy, C], spec_x [B*N, 2*kpx, C]. */
+size_t rpde_fspectral2d_ws_bytes(int B, int M, int N, int C, int K);
+size_t rpde_fspectral2d_spec_elems(int B, int M, int N, int C, int K, int axis /*0:y 1:x*/);
+int rpde_fspectral2d_fwd(const float* x, const float* w_y, const float* w_x, float* out,
+                         float* spec_y, float* spec_x,
+                         int B, int M, int N, int C, int K, int mode,
+                         void* ws, size_t ws_bytes, void* stream);
+int rpde_fspectral2d_bwd(const float* grad_out, const float* spec_y, const float* spec_x,
+                         const float* w_y, const float* w_x,
+                         float* grad_x, float* grad_wy, float* grad_wx,
+                         int B, int M, int N, int C, int K, int mode,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- SpectralConv1d.forward  (models/spectral_convolution.py:38-55)
+ * x [B,Cin,n] channels-first, w [Cin,Cout,K] complex64 (interleaved floats),
+ * out [B,Cout,n]; norm 'backward'.  K > n/2+1 -> RPDE_ERR_MODES (quirk Q5).
+ * act_in: activation applied to x while it is read (the FNO block feeds
+ * act(previous pre-activation), fno_blocks.py:33).  spec_in [B*Cin, 2*kp]. */
+size_t rpde_spectral1d_ws_bytes(int B, int Cin, int Cout, int n, int K);
+int rpde_spectral1d_fwd(const float* x, const float* w, float* out, float* spec_in,
+                        int B, int Cin, int Cout, int n, int K, int act_in,
+                        void* ws, size_t ws_bytes, void* stream);
+int rpde_spectral1d_bwd(const float* grad_out, const float* spec_in, const float* w,
+                        const float* x, float* grad_x, float* grad_w,
+                        int B, int Cin, int Cout, int n, int K, int act_in,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---- SpectralConv2d.forward  (models/spectral_convolution.py:79-98)
+ * x [B,Cin,M,N], w1,w2 [Cin,Cout,m1,m2] complex64, out [B,Cout,M,N]; rows
+ * [0,m1) use w1, rows [M-m1,M) use w2 and win on overlap (quirk Q6).
+ * spec_in [B*Cin, 2*R, m2p] planar (R = 2*m1 retained rows). */
+size_t rpde_spectral2d_ws_bytes(int B, int Cin, int Cout, int M, int N, int m1, int m2);
+size_t rpde_spectral2d_spec_elems(int B, int Cin, int M, int N, int m1, int m2);
+int rpde_spectral2d_fwd(const float* x, const float* w1, const float* w2, float* out, float* spec_in,
+                        int B, int Cin, int Cout, int M, int N, int m1, int m2, int act_in,
+                        void* ws, size_t ws_bytes, void* stream);
+int rpde_spectral2d_bwd(const float* grad_out, const float* spec_in, const float* w1, const float* w2,
+                        const float* x, float* grad_x, float* grad_w1, float* grad_w2,
+                        int B, int Cin, int Cout, int M, int N, int m1, int m2, int act_in,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---- FeedForward  (models/custom_layer.py:49-68) + the residual glue of
+ * FFNO*.forward (models/ffno.py:118,230) and FSpectralConv1d's act (:154).
+ * x [P,dim] channels-last points.  Per layer l: z_l = in_l @ W_l^T + b_l is
+ * stored in zs[l] ([P,out_l]); in_{l+1} = gelu(dropout(z_l)) is applied while
+ * z_l is staged for the next GEMM, never materialised.  The last layer:
+ * out = residual + post_act( LayerNorm( dropout(z_last) ) )   (LN optional,
+ * residual may be NULL).  Dropout masks come from a counter hash of
+ * (seed, layer, element) and are regenerated in backward. */
+typedef struct {
+  int n_layers; int dim; int factor;
+  int layer_norm; float ln_eps;
+  float dropout_p; uint64_t seed;      /* p = 0 in eval mode                         */
+  int post_act;                        /* RPDE_ACT_*                                 */
+  const float* const* weights;         /* [n_layers] W_l [out_l, in_l]               */
+  const float* const* biases;          /* [n_layers] b_l [out_l]                     */
+  const float* ln_gamma; const float* ln_beta;
+} rpde_ff_params;
+size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers);
+int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual,
+                         float* const* zs, float* out, int64_t P,
+                         void* ws, size_t ws_bytes, void* stream);
+int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* const* zs,
+                         const float* grad_out, float* grad_x,
+                         float* const* grad_weights, float* const* grad_biases,
+                         float* grad_gamma, float* grad_beta, int64_t P,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- pointwise linear, channels-last: nn.Linear / WNLinear applied to
+ * [P,in] (models/ffno.py:113,121,225,233; custom_layer.py:70).  Weight-norm is
+ * resolved by the caller into an effective weight. */
+size_t rpde_linear_ws_bytes(int64_t P, int in_f, int out_f);
+int rpde_linear_fwd(const float* x, const float* w, const float* b, float* out,
+                    int64_t P, int in_f, int out_f, void* stream);
+int rpde_linear_bwd(const float* x, const float* w, const float* grad_out,
+                    float* grad_x, float* grad_w, float* grad_b,
+                    int64_t P, int in_f, int out_f, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- 1x1 convolution, channels-first: nn.Conv1d/Conv2d(k=1) lifting, bypass
+ * and projection (models/fno.py:30,93; fno_blocks.py:29,38-39,67,76-77).
+ * x [B,Cin,S], w [Cout,Cin], out [B,Cout,S] (S = flattened spatial size).
+ * act_in is applied to x while staged; accumulate adds into out (the FNO
+ * block's spectral_conv(x) + bypass_conv(x)). */
+size_t rpde_conv1x1_ws_bytes(int B, int Cin, int Cout, int64_t S);
+int rpde_conv1x1_fwd(const float* x, const float* w, const float* b, float* out,
+                     int B, int Cin, int Cout, int64_t S, int act_in, int accumulate, void* stream);
+int rpde_conv1x1_bwd(const float* x, const float* w, const float* grad_out,
+                     float* grad_x, float* grad_w, float* grad_b,
+                     int B, int Cin, int Cout, int64_t S, int act_in, int accumulate_gx,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- grid channels + layout change at the model boundary
+ * (models/ffno.py:92,201-222; fno.py:51,121-139): builds the lifted input
+ * [.., Cin+G] (channels-last) or [B,Cin+G,S] (channels-first) with
+ * endpoint-inclusive linspace coordinates (quirk Q10) generated on device. */
+int rpde_concat_grid(const float* x, float* out, int B, int Cin, int M, int N /*1 for 1-D*/,
+                     int grid_dims /*0,1,2*/, double lo, double hi, int channels_last,
+                     const float* gridx, const float* gridy, void* stream);
+/* [B,S,C] <-> [B,C,S] */
+int rpde_transpose_cs(const float* in, float* out, int B, int64_t S, int C, int to_channels_first, void* stream);
+
+/* ---- elementwise activation: out = act(x); backward dx = g * act'(x) */
+int rpde_act_fwd(const float* x, float* out, int64_t n, int act, void* stream);
+int rpde_act_bwd(const float* x, const float* g, float* dx, int64_t n, int act, void* stream);
+
+/* ---- RelativeL2Loss.forward (utils/loss.py:31-59): rel[b] = |x-y|_2/(|y|_2+1e-8).
+ * rel [B]; loss scalar = mean (size_average) or sum; pass loss=NULL for
+ * reduction=False.  stats (rpde_rel_l2_stats_elems(B) floats: per-sample diff
+ * norm and y norm, then scratch partials) is kept for backward. */
+int64_t rpde_rel_l2_stats_elems(int B);
+int rpde_rel_l2_fwd(const float* x, const float* y, float* rel, float* loss, float* stats,
+                    int B, int64_t per, int size_average, void* stream);
+/* grad_rel [B] if reduction=False else NULL with grad_loss a device scalar */
+int rpde_rel_l2_bwd(const float* x, const float* y, const float* stats,
+                    const float* grad_loss, const float* grad_rel, float* grad_x,
+                    int B, int64_t per, int size_average, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPDE_H */

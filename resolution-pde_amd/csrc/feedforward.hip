@@ -1,0 +1,277 @@
+// FeedForward (models/custom_layer.py:49-68) and the pointwise linears /
+// 1x1 convolutions around the spectral layers, as fp32-MFMA GEMMs.
+//
+// Forward keeps only the pre-activations z_l in HBM.  h_l = gelu(dropout(z_l))
+// is recomputed while z_l is staged into LDS for the next GEMM (forward), for
+// the weight-gradient GEMM (backward) and inside the backward-data epilogue, so
+// the 4x wider hidden activations are written once and never re-materialised.
+#include "rpde_internal.h"
+#include "pointwise.h"
+
+namespace rpde {
+
+static inline uint64_t layer_seed(uint64_t seed, int l) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(l + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static inline int ff_in(const rpde_ff_params* p, int l) { return l == 0 ? p->dim : p->dim * p->factor; }
+static inline int ff_out(const rpde_ff_params* p, int l) { return l == p->n_layers - 1 ? p->dim : p->dim * p->factor; }
+
+static inline int wgrad_split(long P, int out_f, int in_f) {
+  const int tiles = ((out_f + 127) / 128) * ((in_f + 127) / 128);
+  long s = 768 / tiles;
+  const long cap = (P + 127) / 128;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  if (s > 1024) s = 1024;
+  return (int)s;
+}
+
+// y[P,out] = act_in(x)[P,in] . W[out,in]^T + b
+static int linear_fwd_impl(const float* x, const float* w, const float* b, float* y, long P, int in_f, int out_f, int act_in,
+                           float drop_p, uint64_t drop_seed, hipStream_t st) {
+  rpde_gemm_desc d = gemm_desc();
+  d.A = x; d.a_kmajor = 1; d.lda = in_f;
+  d.B = w; d.b_kmajor = 1; d.ldb = in_f;
+  d.C = y; d.ldc = out_f;
+  d.M = (int)P; d.N = out_f; d.K = in_f;
+  d.bias = b; d.bias_mode = b ? 1 : 0;
+  d.act_a = act_in; d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f;
+  return launch_gemm(d, st);
+}
+
+// gw[out,in] = gy[P,out]^T . act_in(x)[P,in]   (split over P, slabs reduced here);  gb = colsum(gy)
+static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, long P, int in_f, int out_f, int act_in,
+                             float drop_p, uint64_t drop_seed, float* ws_slabs, float* ws_colsum, hipStream_t st) {
+  if (gw) {
+    const int S = wgrad_split(P, out_f, in_f);
+    rpde_gemm_desc d = gemm_desc();
+    d.A = gy; d.a_kmajor = 0; d.lda = out_f;
+    d.B = x; d.b_kmajor = 0; d.ldb = in_f;
+    d.M = out_f; d.N = in_f; d.K = (int)P;
+    d.act_b = act_in; d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f;
+    if (S > 1) {
+      d.C = ws_slabs; d.ldc = in_f; d.ksplit = S; d.sCk = (long)out_f * in_f;
+      RPDE_TRY(launch_gemm(d, st));
+      RPDE_TRY(reduce_slabs(ws_slabs, gw, (long)out_f * in_f, S, (long)out_f * in_f, 1.f, 0, st));
+    } else {
+      d.C = gw; d.ldc = in_f;
+      RPDE_TRY(launch_gemm(d, st));
+    }
+  }
+  if (gb) RPDE_TRY(colsum(gy, gb, P, out_f, out_f, ws_colsum, 0, st));
+  return RPDE_OK;
+}
+
+// gx[P,in] = gy[P,out] . W[out,in]   (optionally through act': * act'(drop(z)) * dropscale)
+static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f, int epi_dact,
+                             const float* z, float drop_p, uint64_t drop_seed, hipStream_t st) {
+  rpde_gemm_desc d = gemm_desc();
+  d.A = gy; d.a_kmajor = 1; d.lda = out_f;
+  d.B = w; d.b_kmajor = 0; d.ldb = in_f;
+  d.C = gx; d.ldc = in_f;
+  d.M = (int)P; d.N = in_f; d.K = out_f;
+  d.epi_dact = epi_dact; d.aux = z; d.ldaux = in_f;
+  d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f;
+  return launch_gemm(d, st);
+}
+
+static size_t wgrad_ws_floats(long P, int in_f, int out_f) {
+  const int S = wgrad_split(P, out_f, in_f);
+  return (S > 1 ? (size_t)S * out_f * in_f : 0);
+}
+
+}  // namespace rpde
+
+using namespace rpde;
+
+extern "C" {
+
+// ------------------------------ FeedForward --------------------------------
+size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
+  const int hid = n_layers > 1 ? dim * factor : dim;
+  size_t slabs = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const int i = l == 0 ? dim : dim * factor, o = l == n_layers - 1 ? dim : dim * factor;
+    const size_t s = wgrad_ws_floats(P, i, o);
+    if (s > slabs) slabs = s;
+  }
+  size_t small = colsum_ws_floats(P, hid);
+  const size_t t = ff_tail_bwd_ws_floats(P, dim);
+  if (t > small) small = t;
+  return 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small);
+}
+
+int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* zs, float* out,
+                         int64_t P, void* ws, size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(p && x && zs && out && P > 0, "feedforward_fwd: bad arguments");
+  RPDE_CHECK_ARG(p->n_layers >= 1 && p->dim > 0 && p->factor > 0, "feedforward_fwd: bad shape");
+  RPDE_CHECK_ARG(P < (1L << 31), "feedforward_fwd: too many points for one call");
+  RPDE_CHECK_ARG(p->dropout_p >= 0.f && p->dropout_p < 1.f, "feedforward_fwd: dropout %f", p->dropout_p);
+  hipStream_t st = as_stream(stream);
+  (void)ws; (void)ws_bytes;
+  const int L = p->n_layers;
+  for (int l = 0; l < L; ++l) {
+    RPDE_CHECK_ARG(zs[l] && p->weights[l], "feedforward_fwd: null layer %d buffers", l);
+    const float* in = l == 0 ? x : zs[l - 1];
+    RPDE_TRY(linear_fwd_impl(in, p->weights[l], p->biases ? p->biases[l] : nullptr, zs[l], P, ff_in(p, l), ff_out(p, l),
+                             l == 0 ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU, l == 0 ? 0.f : p->dropout_p,
+                             layer_seed(p->seed, l - 1), st));
+  }
+  return ff_tail_fwd(zs[L - 1], residual, out, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
+                     make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, st);
+}
+
+int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* const* zs, const float* grad_out,
+                         float* grad_x, float* const* grad_weights, float* const* grad_biases, float* grad_gamma,
+                         float* grad_beta, int64_t P, void* ws, size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(p && x && zs && grad_out && P > 0, "feedforward_bwd: bad arguments");
+  RPDE_CHECK_ARG(P < (1L << 31), "feedforward_bwd: too many points for one call");
+  hipStream_t st = as_stream(stream);
+  const int L = p->n_layers;
+  const int hid = L > 1 ? p->dim * p->factor : p->dim;
+  Arena ar(ws, ws_bytes);
+  float* buf0 = ar.take((size_t)P * hid);
+  float* buf1 = ar.take((size_t)P * hid);
+  size_t slabs_n = 0;
+  for (int l = 0; l < L; ++l) { const size_t s = wgrad_ws_floats(P, ff_in(p, l), ff_out(p, l)); if (s > slabs_n) slabs_n = s; }
+  float* slabs = ar.take(slabs_n);
+  size_t small_n = colsum_ws_floats(P, hid);
+  if (ff_tail_bwd_ws_floats(P, p->dim) > small_n) small_n = ff_tail_bwd_ws_floats(P, p->dim);
+  float* small = ar.take(small_n);
+  if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
+
+  // tail: d(out) -> dz_{L-1}, d(gamma), d(beta)
+  float* dz = buf0;
+  float* other = buf1;
+  RPDE_TRY(ff_tail_bwd(zs[L - 1], grad_out, dz, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
+                       make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, grad_gamma, grad_beta, small, st));
+  for (int l = L - 1; l >= 0; --l) {
+    const int in_f = ff_in(p, l), out_f = ff_out(p, l);
+    const float* in = l == 0 ? x : zs[l - 1];
+    const int act_in = l == 0 ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU;
+    const float dp = l == 0 ? 0.f : p->dropout_p;
+    const uint64_t sd = layer_seed(p->seed, l - 1);
+    RPDE_TRY(linear_wgrad_impl(in, dz, grad_weights ? grad_weights[l] : nullptr, grad_biases ? grad_biases[l] : nullptr, P,
+                               in_f, out_f, act_in, dp, sd, slabs, small, st));
+    if (l > 0) {
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, RPDE_ACT_GELU, zs[l - 1], dp, sd, st));
+      float* t = dz; dz = other; other = t;
+    } else if (grad_x) {
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, 0, nullptr, 0.f, 0, st));
+    }
+  }
+  return RPDE_OK;
+}
+
+// ------------------------------ nn.Linear ----------------------------------
+size_t rpde_linear_ws_bytes(int64_t P, int in_f, int out_f) {
+  return arena_bytes(wgrad_ws_floats(P, in_f, out_f)) + arena_bytes(colsum_ws_floats(P, out_f));
+}
+
+int rpde_linear_fwd(const float* x, const float* w, const float* b, float* out, int64_t P, int in_f, int out_f, void* stream) {
+  RPDE_CHECK_ARG(x && w && out && P > 0 && in_f > 0 && out_f > 0 && P < (1L << 31), "linear_fwd: bad arguments");
+  return linear_fwd_impl(x, w, b, out, P, in_f, out_f, RPDE_ACT_IDENTITY, 0.f, 0, as_stream(stream));
+}
+
+int rpde_linear_bwd(const float* x, const float* w, const float* grad_out, float* grad_x, float* grad_w, float* grad_b,
+                    int64_t P, int in_f, int out_f, void* ws, size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(x && w && grad_out && P > 0 && in_f > 0 && out_f > 0 && P < (1L << 31), "linear_bwd: bad arguments");
+  hipStream_t st = as_stream(stream);
+  Arena ar(ws, ws_bytes);
+  float* slabs = ar.take(wgrad_ws_floats(P, in_f, out_f));
+  float* small = ar.take(colsum_ws_floats(P, out_f));
+  if (!ar.ok()) { set_error("linear_bwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  RPDE_TRY(linear_wgrad_impl(x, grad_out, grad_w, grad_b, P, in_f, out_f, RPDE_ACT_IDENTITY, 0.f, 0, slabs, small, st));
+  if (grad_x) RPDE_TRY(linear_dgrad_impl(grad_out, w, grad_x, P, in_f, out_f, 0, nullptr, 0.f, 0, st));
+  return RPDE_OK;
+}
+
+// --------------------------- 1x1 conv, channels-first -----------------------
+// out[b][Cout,S] (+)= W[Cout,Cin] . act_in(x[b])[Cin,S] + bias
+size_t rpde_conv1x1_ws_bytes(int B, int Cin, int Cout, int64_t S) {
+  return arena_bytes((size_t)B * Cout * Cin) + arena_bytes((size_t)B * Cout * 64);
+}
+
+int rpde_conv1x1_fwd(const float* x, const float* w, const float* b, float* out, int B, int Cin, int Cout, int64_t S,
+                     int act_in, int accumulate, void* stream) {
+  RPDE_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && S > 0 && S < (1L << 31), "conv1x1_fwd: bad arguments");
+  rpde_gemm_desc d = gemm_desc();
+  d.A = w; d.a_kmajor = 1; d.lda = Cin;
+  d.B = x; d.b_kmajor = 0; d.ldb = S;
+  d.C = out; d.ldc = S;
+  d.M = Cout; d.N = (int)S; d.K = Cin;
+  d.batch = B; d.sB1 = (long)Cin * S; d.sC1 = (long)Cout * S;
+  d.bias = b; d.bias_mode = b ? 2 : 0;
+  d.act_b = act_in; d.accumulate = accumulate;
+  return launch_gemm(d, as_stream(stream));
+}
+
+namespace rpde {
+// gb[c] = sum_{b,s} g[b][c][s]: rows (b,c) of length S -> per-row partial sums, then fold over b
+__global__ __launch_bounds__(256) void k_rowsum64(const float* __restrict__ g, float* __restrict__ part, long S) {
+  // one block per row, 64 partials per row kept for a deterministic second stage
+  __shared__ float red[256];
+  const float* r = g + (long)blockIdx.x * S;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < S; i += 256) acc += r[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) part[(long)blockIdx.x * 64 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+}
+__global__ void k_fold_bias(const float* __restrict__ part, float* __restrict__ gb, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < 64; ++j) acc += part[((long)b * C + c) * 64 + j];
+  gb[c] = acc;
+}
+}  // namespace rpde
+
+int rpde_conv1x1_bwd(const float* x, const float* w, const float* grad_out, float* grad_x, float* grad_w, float* grad_b,
+                     int B, int Cin, int Cout, int64_t S, int act_in, int accumulate_gx, void* ws, size_t ws_bytes,
+                     void* stream) {
+  RPDE_CHECK_ARG(x && w && grad_out && B > 0 && Cin > 0 && Cout > 0 && S > 0 && S < (1L << 31), "conv1x1_bwd: bad arguments");
+  hipStream_t st = as_stream(stream);
+  Arena ar(ws, ws_bytes);
+  float* slabs = ar.take((size_t)B * Cout * Cin);
+  float* part = ar.take((size_t)B * Cout * 64);
+  if (!ar.ok()) { set_error("conv1x1_bwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  if (grad_w) {
+    // gw[o,i] = sum_b sum_s g[b][o][s] * act(x[b][i][s]): one slab per batch entry, reduced over b
+    rpde_gemm_desc d = gemm_desc();
+    d.A = grad_out; d.a_kmajor = 1; d.lda = S;
+    d.B = x; d.b_kmajor = 1; d.ldb = S;
+    d.C = slabs; d.ldc = Cin;
+    d.M = Cout; d.N = Cin; d.K = (int)S;
+    d.batch = B; d.sA1 = (long)Cout * S; d.sB1 = (long)Cin * S; d.sC1 = (long)Cout * Cin;
+    d.act_b = act_in;
+    RPDE_TRY(launch_gemm(d, st));
+    RPDE_TRY(reduce_slabs(slabs, grad_w, (long)Cout * Cin, B, (long)Cout * Cin, 1.f, 0, st));
+  }
+  if (grad_b) {
+    hipLaunchKernelGGL(k_rowsum64, dim3(B * Cout), dim3(256), 0, st, grad_out, part, (long)S);
+    RPDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fold_bias, dim3((Cout + 63) / 64), dim3(64), 0, st, part, grad_b, B, Cout);
+    RPDE_LAUNCH_CHECK();
+  }
+  if (grad_x) {
+    // gx[b][i,s] = sum_o W[o,i] * g[b][o,s]   (through act'(x) when act_in is set)
+    rpde_gemm_desc d = gemm_desc();
+    d.A = w; d.a_kmajor = 0; d.lda = Cin;
+    d.B = grad_out; d.b_kmajor = 0; d.ldb = S;
+    d.C = grad_x; d.ldc = S;
+    d.M = Cin; d.N = (int)S; d.K = Cout;
+    d.batch = B; d.sB1 = (long)Cout * S; d.sC1 = (long)Cin * S;
+    if (act_in) { d.epi_dact = act_in; d.aux = x; d.ldaux = S; }
+    d.accumulate = accumulate_gx;
+    RPDE_TRY(launch_gemm(d, st));
+  }
+  return RPDE_OK;
+}
+
+}  // extern "C"

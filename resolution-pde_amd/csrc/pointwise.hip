@@ -1,0 +1,568 @@
+// HBM-bound pointwise / reduction kernels around the GEMMs.
+// All are coalesced (16 B per lane where the layout allows), wave64 shuffles
+// for row reductions, deterministic two-stage sums (per-block partial slabs,
+// then reduce_slabs) -- no float atomics, so results are run-to-run identical.
+#include "rpde_internal.h"
+#include "pointwise.h"
+
+namespace rpde {
+
+// ---------------------------------------------------------------------------
+// out[i] (+)= scale * sum_s slabs[s*stride + i]
+// ---------------------------------------------------------------------------
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long n, int S, long stride,
+                               float scale, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += slabs[(long)s * stride + i];
+  acc *= scale;
+  if (accumulate) acc += out[i];
+  out[i] = acc;
+}
+
+int reduce_slabs(const float* slabs, float* out, long n, int S, long stride, float scale, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, out, n, S, stride, scale, accumulate);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// column sums of x [P, N] (row stride ld): slab[block][n] partials
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, float* __restrict__ slab, long P, int N, long ld,
+                                                long rows_per_block) {
+  __shared__ float red[256];
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r1 = min(P, r0 + rows_per_block);
+  const int t = threadIdx.x;
+  if (N <= 256 && 256 % N == 0) {
+    const int tr = t / N, c = t % N, step = 256 / N;
+    float acc = 0.f;
+    for (long r = r0 + tr; r < r1; r += step) acc += x[r * ld + c];
+    red[t] = acc;
+    __syncthreads();
+    if (tr == 0) {
+      for (int j = 1; j < step; ++j) acc += red[j * N + c];
+      slab[(long)blockIdx.x * N + c] = acc;
+    }
+  } else {
+    for (int c = t; c < N; c += 256) {
+      float acc = 0.f;
+      for (long r = r0; r < r1; ++r) acc += x[r * ld + c];
+      slab[(long)blockIdx.x * N + c] = acc;
+    }
+  }
+}
+
+size_t colsum_ws_floats(long P, int N) {
+  long nb = (P + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (size_t)nb * N;
+}
+
+int colsum(const float* x, float* out, long P, int N, long ld, float* ws, int accumulate, hipStream_t st) {
+  long nb = (P + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  const long rpb = (P + nb - 1) / nb;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)nb), dim3(256), 0, st, x, ws, P, N, ld, rpb);
+  RPDE_LAUNCH_CHECK();
+  return reduce_slabs(ws, out, N, (int)nb, N, 1.f, accumulate, st);
+}
+
+// ---------------------------------------------------------------------------
+// FeedForward tail: out = residual + post_act( LN( dropout(z) ) )
+// One row of C floats is owned by G = C/4 lanes (float4 each); a wave holds
+// 64/G rows.  C must be a multiple of 4 with C/4 in {1,2,4,...,64}; other
+// widths take the one-wave-per-row path below.
+// ---------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_ff_tail_fwd(const float* __restrict__ z, const float* __restrict__ res,
+                                                     float* __restrict__ out, long P, int layer_norm, float eps,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     DropCfg drop, int post_act) {
+  constexpr int C = 4 * G;
+  const int lane_in_row = threadIdx.x % G;
+  const long rows_per_block = 256 / G;
+  for (long row = (long)blockIdx.x * rows_per_block + threadIdx.x / G; row < P; row += (long)gridDim.x * rows_per_block) {
+    const long off = row * C + lane_in_row * 4;
+    float4 v = *reinterpret_cast<const float4*>(z + off);
+    if (drop.on()) {
+      float s[4];
+      drop_scale4(drop, (uint64_t)off, s);
+      v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
+    }
+    if (layer_norm) {
+      const float mean = group_sum<G>(v.x + v.y + v.z + v.w) * (1.f / C);
+      const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+      const float var = group_sum<G>(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / C);
+      const float rstd = rsqrtf(var + eps);
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + lane_in_row * 4);
+      const float4 bt = *reinterpret_cast<const float4*>(beta + lane_in_row * 4);
+      v.x = dx * rstd * gm.x + bt.x;
+      v.y = dy * rstd * gm.y + bt.y;
+      v.z = dz * rstd * gm.z + bt.z;
+      v.w = dw * rstd * gm.w + bt.w;
+    }
+    if (post_act) {
+      v.x = act_f(post_act, v.x); v.y = act_f(post_act, v.y);
+      v.z = act_f(post_act, v.z); v.w = act_f(post_act, v.w);
+    }
+    if (res) {
+      const float4 r = *reinterpret_cast<const float4*>(res + off);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    *reinterpret_cast<float4*>(out + off) = v;
+  }
+}
+
+// generic width: one wave per row, up to 8 elements per lane (C <= 512)
+__global__ __launch_bounds__(256) void k_ff_tail_fwd_any(const float* __restrict__ z, const float* __restrict__ res,
+                                                         float* __restrict__ out, long P, int C, int layer_norm, float eps,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         DropCfg drop, int post_act) {
+  const int lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < P; row += (long)gridDim.x * 4) {
+    float v[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = 0.f;
+      if (c < C) {
+        const long off = row * C + c;
+        v[j] = z[off];
+        if (drop.on()) v[j] *= drop_scale1(drop, (uint64_t)off);
+        sum += v[j];
+      }
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (layer_norm) {
+      mean = wave_sum(sum) / C;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (lane + 64 * j < C) sq += (v[j] - mean) * (v[j] - mean);
+      rstd = rsqrtf(wave_sum(sq) / C + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) {
+        float y = v[j];
+        if (layer_norm) y = (y - mean) * rstd * gamma[c] + beta[c];
+        y = act_f(post_act, y);
+        const long off = row * C + c;
+        if (res) y += res[off];
+        out[off] = y;
+      }
+    }
+  }
+}
+
+int ff_tail_fwd(const float* z, const float* res, float* out, long P, int C, int layer_norm, float eps,
+                const float* gamma, const float* beta, DropCfg drop, int post_act, hipStream_t st) {
+  RPDE_CHECK_ARG(!layer_norm || (gamma && beta), "ff_tail: layer_norm needs gamma/beta");
+  const int G = C / 4;
+  const bool vec = (C % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64);
+  if (!vec) {
+    RPDE_CHECK_ARG(C <= 512, "ff_tail: width %d > 512 unsupported", C);
+    long nb = (P + 3) / 4; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_ff_tail_fwd_any, dim3((unsigned)nb), dim3(256), 0, st, z, res, out, P, C, layer_norm, eps, gamma, beta, drop, post_act);
+    RPDE_LAUNCH_CHECK();
+    return RPDE_OK;
+  }
+  const long rpb = 256 / G;
+  long nb = (P + rpb - 1) / rpb; if (nb > 8192) nb = 8192;
+#define LAUNCH_G(GG) hipLaunchKernelGGL((k_ff_tail_fwd<GG>), dim3((unsigned)nb), dim3(256), 0, st, z, res, out, P, layer_norm, eps, gamma, beta, drop, post_act)
+  switch (G) {
+    case 1: LAUNCH_G(1); break; case 2: LAUNCH_G(2); break; case 4: LAUNCH_G(4); break;
+    case 8: LAUNCH_G(8); break; case 16: LAUNCH_G(16); break; case 32: LAUNCH_G(32); break;
+    default: LAUNCH_G(64); break;
+  }
+#undef LAUNCH_G
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// backward of the tail.  g = d(out).  Produces dz (through post_act', LN and
+// the dropout mask) and per-block partial sums for d(gamma), d(beta):
+// slab[block][0:C] = sum dy*xhat, slab[block][C:2C] = sum dy.
+// One wave per row (any C <= 512): simple and HBM bound.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ff_tail_bwd(const float* __restrict__ z, const float* __restrict__ g,
+                                                     float* __restrict__ dz, float* __restrict__ slab, long P, int C,
+                                                     int layer_norm, float eps, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, DropCfg drop, int post_act) {
+  __shared__ float red[4][2][512];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float dg[8], db[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+  for (long row = (long)blockIdx.x * 4 + w; row < P; row += (long)gridDim.x * 4) {
+    float t[8], s[8], gy[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + 64 * j;
+      t[j] = 0.f; s[j] = 1.f; gy[j] = 0.f;
+      if (c < C) {
+        const long off = row * C + c;
+        if (drop.on()) s[j] = drop_scale1(drop, (uint64_t)off);
+        t[j] = z[off] * s[j];
+        gy[j] = g[off];
+        sum += t[j];
+      }
+    }
+    if (!layer_norm) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) dz[row * C + c] = gy[j] * dact_f(post_act, t[j]) * s[j];
+      }
+      continue;
+    }
+    const float mean = wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (lane + 64 * j < C) sq += (t[j] - mean) * (t[j] - mean);
+    const float rstd = rsqrtf(wave_sum(sq) / C + eps);
+    float xh[8], dxh[8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + 64 * j;
+      xh[j] = 0.f; dxh[j] = 0.f;
+      if (c < C) {
+        xh[j] = (t[j] - mean) * rstd;
+        const float gm = gamma[c];
+        float dy = gy[j];
+        if (post_act) dy *= dact_f(post_act, xh[j] * gm + beta[c]);
+        dg[j] += dy * xh[j];
+        db[j] += dy;
+        dxh[j] = dy * gm;
+        s1 += dxh[j];
+        s2 += dxh[j] * xh[j];
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) dz[row * C + c] = rstd * (dxh[j] - s1 - xh[j] * s2) * s[j];
+    }
+  }
+  if (!layer_norm) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[w][0][lane + 64 * j] = dg[j];
+    red[w][1][lane + 64 * j] = db[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    slab[(long)blockIdx.x * 2 * C + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+    slab[(long)blockIdx.x * 2 * C + C + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+  }
+}
+
+static long tail_bwd_blocks(long P) {
+  long nb = (P + 3) / 4;
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+size_t ff_tail_bwd_ws_floats(long P, int C) { return (size_t)tail_bwd_blocks(P) * 2 * C; }
+
+int ff_tail_bwd(const float* z, const float* g, float* dz, long P, int C, int layer_norm, float eps, const float* gamma,
+                const float* beta, DropCfg drop, int post_act, float* grad_gamma, float* grad_beta, float* ws,
+                hipStream_t st) {
+  RPDE_CHECK_ARG(C <= 512, "ff_tail_bwd: width %d > 512 unsupported", C);
+  const long nb = tail_bwd_blocks(P);
+  hipLaunchKernelGGL(k_ff_tail_bwd, dim3((unsigned)nb), dim3(256), 0, st, z, g, dz, ws, P, C, layer_norm, eps, gamma, beta, drop, post_act);
+  RPDE_LAUNCH_CHECK();
+  if (layer_norm) {
+    if (grad_gamma) RPDE_TRY(reduce_slabs(ws, grad_gamma, C, (int)nb, 2L * C, 1.f, 0, st));
+    if (grad_beta) RPDE_TRY(reduce_slabs(ws + C, grad_beta, C, (int)nb, 2L * C, 1.f, 0, st));
+  }
+  return RPDE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-mode complex weights [Ci,Co,K,2] <-> real block matrices [k][2Ci][2Co]
+//   (re,i)->(re,o): Wr   (im,i)->(re,o): -Wi   (re,i)->(im,o): Wi   (im,i)->(im,o): Wr
+// ---------------------------------------------------------------------------
+__global__ void k_pack_mix(const float* __restrict__ w, float* __restrict__ blk, int Ci, int Co, int K, int keff) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = 4L * Ci * Co;
+  if (idx >= per * keff) return;
+  const int k = (int)(idx / per);
+  const long r = idx % per;
+  const int row = (int)(r / (2 * Co)), col = (int)(r % (2 * Co));
+  const int ri_in = row / Ci, i = row % Ci, ri_out = col / Co, o = col % Co;
+  const float* p = w + (((long)i * Co + o) * K + k) * 2;
+  float v;
+  if (ri_in == ri_out) v = p[0];
+  else v = ri_in ? -p[1] : p[1];
+  blk[idx] = v;
+}
+
+int pack_mix_weights(const float* w, float* blk, int Ci, int Co, int K, int keff, hipStream_t st) {
+  const long tot = 4L * Ci * Co * keff;
+  hipLaunchKernelGGL(k_pack_mix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, blk, Ci, Co, K, keff);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+// gw[i,o,k,:] = fold( sum_s slab[s][k][2Ci][2Co] ), zero for k >= keff
+__global__ void k_unpack_mix_grad(const float* __restrict__ slabs, float* __restrict__ gw, int Ci, int Co, int K, int keff,
+                                  int S, long sstride) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Ci * Co * K) return;
+  const int k = (int)(idx % K);
+  const long io = idx / K;
+  const int o = (int)(io % Co), i = (int)(io / Co);
+  float gr = 0.f, gi = 0.f;
+  if (k < keff) {
+    const long per = 4L * Ci * Co, ld = 2L * Co;
+    for (int s = 0; s < S; ++s) {
+      const float* b = slabs + (long)s * sstride + (long)k * per;
+      gr += b[(long)i * ld + o] + b[(long)(Ci + i) * ld + Co + o];
+      gi += b[(long)i * ld + Co + o] - b[(long)(Ci + i) * ld + o];
+    }
+  }
+  gw[idx * 2] = gr;
+  gw[idx * 2 + 1] = gi;
+}
+
+int unpack_mix_grad(const float* slabs, float* gw, int Ci, int Co, int K, int keff, int S, long sstride, hipStream_t st) {
+  const long tot = (long)Ci * Co * K;
+  hipLaunchKernelGGL(k_unpack_mix_grad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, gw, Ci, Co, K, keff, S, sstride);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// relative L2 loss
+// ---------------------------------------------------------------------------
+constexpr int L2_BLOCKS = 64;   // partial blocks per sample
+
+__global__ __launch_bounds__(256) void k_rel_l2_partial(const float* __restrict__ x, const float* __restrict__ y,
+                                                        float* __restrict__ part, long per) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.y;
+  const float* xb = x + (long)b * per;
+  const float* yb = y + (long)b * per;
+  float sd = 0.f, sy = 0.f;
+  const bool vec = (per % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  if (vec) {
+    const long nv = per / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+      const float4 a = reinterpret_cast<const float4*>(xb)[i];
+      const float4 c = reinterpret_cast<const float4*>(yb)[i];
+      const float d0 = a.x - c.x, d1 = a.y - c.y, d2 = a.z - c.z, d3 = a.w - c.w;
+      sd += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      sy += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+      const float d = xb[i] - yb[i];
+      sd += d * d;
+      sy += yb[i] * yb[i];
+    }
+  }
+  sd = wave_sum(sd);
+  sy = wave_sum(sy);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = sd; red[1][w] = sy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((long)b * gridDim.x + blockIdx.x) * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    part[((long)b * gridDim.x + blockIdx.x) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// one block: stats[b] = (|x-y|, |y|), rel[b], loss = mean/sum
+__global__ void k_rel_l2_final(const float* __restrict__ part, int nblk, float* __restrict__ rel, float* __restrict__ loss,
+                               float* __restrict__ stats, int B, int size_average) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float sd = 0.f, sy = 0.f;
+    for (int j = 0; j < nblk; ++j) { sd += part[((long)b * nblk + j) * 2]; sy += part[((long)b * nblk + j) * 2 + 1]; }
+    const float dn = sqrtf(sd), yn = sqrtf(sy);
+    const float r = dn / (yn + 1e-8f);
+    stats[2 * b] = dn; stats[2 * b + 1] = yn;
+    if (rel) rel[b] = r;
+    acc += r;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && loss) *loss = size_average ? red[0] / B : red[0];
+}
+
+__global__ __launch_bounds__(256) void k_rel_l2_bwd(const float* __restrict__ x, const float* __restrict__ y,
+                                                    const float* __restrict__ stats, const float* __restrict__ grad_loss,
+                                                    const float* __restrict__ grad_rel, float* __restrict__ gx, int B, long per,
+                                                    int size_average) {
+  const int b = blockIdx.y;
+  const float dn = stats[2 * b], yn = stats[2 * b + 1];
+  float gr = grad_rel ? grad_rel[b] : (size_average ? grad_loss[0] / B : grad_loss[0]);
+  const float coef = dn > 0.f ? gr / (dn * (yn + 1e-8f)) : 0.f;
+  const float* xb = x + (long)b * per;
+  const float* yb = y + (long)b * per;
+  float* gb = gx + (long)b * per;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) gb[i] = coef * (xb[i] - yb[i]);
+}
+
+}  // namespace rpde
+
+using namespace rpde;
+
+extern "C" {
+
+int rpde_rel_l2_fwd(const float* x, const float* y, float* rel, float* loss, float* stats, int B, int64_t per,
+                    int size_average, void* stream) {
+  RPDE_CHECK_ARG(x && y && stats && B > 0 && per > 0, "rel_l2_fwd: bad arguments");
+  hipStream_t st = as_stream(stream);
+  // partial sums live behind the stats the caller keeps: stats has 2*B floats,
+  // the partials need 2*B*L2_BLOCKS more -> caller allocates stats with
+  // rpde_rel_l2_stats_elems(B) floats.
+  float* part = stats + 2L * B;
+  hipLaunchKernelGGL(k_rel_l2_partial, dim3(L2_BLOCKS, B), dim3(256), 0, st, x, y, part, (long)per);
+  RPDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_rel_l2_final, dim3(1), dim3(256), 0, st, part, L2_BLOCKS, rel, loss, stats, B, size_average);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+int64_t rpde_rel_l2_stats_elems(int B) { return 2L * B * (1 + L2_BLOCKS); }
+
+int rpde_rel_l2_bwd(const float* x, const float* y, const float* stats, const float* grad_loss, const float* grad_rel,
+                    float* grad_x, int B, int64_t per, int size_average, void* stream) {
+  RPDE_CHECK_ARG(x && y && stats && grad_x && (grad_loss || grad_rel), "rel_l2_bwd: bad arguments");
+  long nb = (per + 1023) / 1024; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_rel_l2_bwd, dim3((unsigned)nb, B), dim3(256), 0, as_stream(stream), x, y, stats, grad_loss, grad_rel, grad_x, B, (long)per, size_average);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// layout helpers at the model boundary
+// ---------------------------------------------------------------------------
+namespace rpde {
+
+// out (channels-last [B,S,Ct] or channels-first [B,Ct,S]) = cat(x [B,Cin,S], grid coords)
+__global__ void k_concat_grid(const float* __restrict__ x, float* __restrict__ out, int B, int Cin, int M, int N, int G,
+                              double lo, double hi, int channels_last, const float* __restrict__ gx,
+                              const float* __restrict__ gy) {
+  const long S = (long)M * N;
+  const int Ct = Cin + G;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * S * Ct) return;
+  int c; long s; int b;
+  if (channels_last) { c = (int)(idx % Ct); s = (idx / Ct) % S; b = (int)(idx / (Ct * S)); }
+  else { s = idx % S; c = (int)((idx / S) % Ct); b = (int)(idx / (S * Ct)); }
+  float v;
+  if (c < Cin) {
+    v = x[((long)b * Cin + c) * S + s];
+  } else {
+    const int axis = c - Cin;                 // 0: first spatial dim, 1: second
+    const int len = (G == 2 && axis == 1) ? N : M;
+    const int pos = (G == 2) ? (axis == 0 ? (int)(s / N) : (int)(s % N)) : (int)s;
+    const float* tab = axis == 0 ? gx : gy;
+    if (tab) v = tab[pos];
+    else {
+      // numpy.linspace(lo, hi, len) in double, then cast (quirk Q10)
+      const double step = len > 1 ? (hi - lo) / (double)(len - 1) : 0.0;
+      v = (pos == len - 1 && len > 1) ? (float)hi : (float)(lo + step * pos);
+    }
+  }
+  out[idx] = v;
+}
+
+// tiled transpose [B,S,C] <-> [B,C,S]
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, float* __restrict__ out, long R, long Cc) {
+  // in [B][R][Cc] -> out [B][Cc][R]
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* ib = in + (long)b * R * Cc;
+  float* ob = out + (long)b * R * Cc;
+  for (int j = ty; j < 32; j += 8) {
+    const long r = r0 + j, c = c0 + tx;
+    if (r < R && c < Cc) tile[j][tx] = ib[r * Cc + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const long c = c0 + j, r = r0 + tx;
+    if (r < R && c < Cc) ob[c * R + r] = tile[tx][j];
+  }
+}
+
+__global__ void k_act_fwd(const float* __restrict__ x, float* __restrict__ out, long n, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = act_f(act, x[i]);
+}
+__global__ void k_act_bwd(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dx, long n, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = g[i] * dact_f(act, x[i]);
+}
+
+}  // namespace rpde
+
+extern "C" {
+
+int rpde_concat_grid(const float* x, float* out, int B, int Cin, int M, int N, int grid_dims, double lo, double hi,
+                     int channels_last, const float* gridx, const float* gridy, void* stream) {
+  RPDE_CHECK_ARG(x && out && B > 0 && Cin > 0 && M > 0 && N > 0, "concat_grid: bad arguments");
+  RPDE_CHECK_ARG(grid_dims >= 0 && grid_dims <= 2, "concat_grid: grid_dims %d", grid_dims);
+  const long tot = (long)B * M * N * (Cin + grid_dims);
+  hipLaunchKernelGGL(k_concat_grid, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream), x, out, B, Cin, M, N, grid_dims, lo, hi, channels_last, gridx, gridy);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+int rpde_transpose_cs(const float* in, float* out, int B, int64_t S, int C, int to_channels_first, void* stream) {
+  RPDE_CHECK_ARG(in && out && B > 0 && S > 0 && C > 0, "transpose_cs: bad arguments");
+  const long R = to_channels_first ? S : C, Cc = to_channels_first ? C : S;
+  dim3 grid((unsigned)((Cc + 31) / 32), (unsigned)((R + 31) / 32), B);
+  RPDE_CHECK_ARG(grid.y <= 65535 && B <= 65535, "transpose_cs: tensor too large for one launch");
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, as_stream(stream), in, out, R, Cc);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+int rpde_act_fwd(const float* x, float* out, int64_t n, int act, void* stream) {
+  RPDE_CHECK_ARG(x && out && n >= 0, "act_fwd: bad arguments");
+  if (n == 0) return RPDE_OK;
+  hipLaunchKernelGGL(k_act_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, out, (long)n, act);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+int rpde_act_bwd(const float* x, const float* g, float* dx, int64_t n, int act, void* stream) {
+  RPDE_CHECK_ARG(x && g && dx && n >= 0, "act_bwd: bad arguments");
+  if (n == 0) return RPDE_OK;
+  hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, g, dx, (long)n, act);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""FNO1d / FNO2d (reference: models/fno.py:24-150): grid concat -> 1x1 lifting
+-> n_blocks x act(spectral + bypass) -> 1x1 projection MLP, channels-first."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from models.fno_blocks import FNOBlock1d, FNOBlock2d, LinearMLP1d, MLP1d, MLP2d, act_name  # noqa: F401
+from rpde import ops
+
+
+def _coord(c, device):
+    if c is None:
+        return None
+    if not isinstance(c, torch.Tensor):
+        c = torch.tensor(c, dtype=torch.float)
+    return c.to(device=device, dtype=torch.float32).contiguous()
+
+
+class _FNO(nn.Module):
+    def _run(self, lifted):
+        h = ops.conv1x1(lifted, self.lifting.weight, self.lifting.bias)
+        act_in = "identity"
+        for blk in self.fno_blocks:          # h holds the pre-activation of the previous block
+            h = blk.pre_activation(h, act_in)
+            act_in = act_name(blk.activation)
+        return self.projection(h, act_in)
+
+
+class FNO1d(_FNO):
+    def __init__(self, in_channels, out_channels, modes, width, grid=None, activation=F.relu, n_blocks=4):
+        super().__init__()
+        self.width, self.grid = width, grid
+        self.lifting = nn.Conv1d(in_channels + 1, width, 1)
+        self.fno_blocks = nn.ModuleList([FNOBlock1d(width, width, modes, activation) for _ in range(n_blocks)])
+        self.projection = MLP1d(width, out_channels, width * 4)
+
+    def get_grid(self, shape, device):
+        """[B,n,1] coordinates: the user grid or linspace(0, 2*pi, n) (endpoint included)."""
+        b, n = shape[0], shape[1]
+        g = _coord(self.grid, device) if self.grid is not None else torch.tensor(
+            np.linspace(0, 2 * np.pi, n), dtype=torch.float).to(device)
+        return g.reshape(1, n, 1).repeat([b, 1, 1])
+
+    def forward(self, x):
+        gx = _coord(self.grid, x.device) if self.grid is not None else None
+        return self._run(ops.concat_grid(x, 1, 0.0, 2 * np.pi, channels_last=False, gridx=gx))
+
+
+class FNO2d(_FNO):
+    def __init__(self, in_channels, out_channels, modes1, modes2, width, grid=None, activation=F.gelu, n_blocks=4):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.modes1, self.modes2, self.width, self.grid = modes1, modes2, width, grid
+        self.lifting = nn.Conv2d(in_channels + 2, width, 1)
+        self.fno_blocks = nn.ModuleList(
+            [FNOBlock2d(width, width, modes1, modes2, activation) for _ in range(n_blocks)])
+        self.projection = MLP2d(width, out_channels, width * 4)
+
+    def get_grid(self, shape, device):
+        """[B,M,N,2] coordinates (x then y), linspace(0,1) with the endpoint."""
+        b, m, n = shape[0], shape[1], shape[2]
+        if self.grid is not None:
+            gx, gy = _coord(self.grid[0], device), _coord(self.grid[1], device)
+        else:
+            gx = torch.tensor(np.linspace(0, 1, m), dtype=torch.float).to(device)
+            gy = torch.tensor(np.linspace(0, 1, n), dtype=torch.float).to(device)
+        gx = gx.reshape(1, m, 1, 1).repeat([b, 1, n, 1])
+        gy = gy.reshape(1, 1, n, 1).repeat([b, m, 1, 1])
+        return torch.cat((gx, gy), dim=-1)
+
+    def forward(self, x):
+        gx = gy = None
+        if self.grid is not None:
+            gx, gy = _coord(self.grid[0], x.device), _coord(self.grid[1], x.device)
+        return self._run(ops.concat_grid(x, 2, 0.0, 1.0, channels_last=False, gridx=gx, gridy=gy))

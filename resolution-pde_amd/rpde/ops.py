@@ -1,0 +1,506 @@
+"""torch.autograd.Function wrappers over the C ABI (include/rpde.h).
+
+PyTorch is plumbing here: it owns device memory (outputs, tensors saved for
+backward, workspaces all come from its caching allocator) and provides the
+current HIP stream.  Every numerical step of the hot path runs in
+librpde_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT, MODE, NORM, check, load, ptr, ptr_array, stream_ptr, workspace
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _as_float_storage(w: torch.Tensor) -> torch.Tensor:
+    """complex64 [..] -> float32 [..,2] view of the same memory"""
+    w = w if w.is_contiguous() else w.contiguous()
+    return torch.view_as_real(w) if w.is_complex() else w
+
+
+# ----------------------------------------------------------------------------
+# FSpectralConv{1,2}d.forward_fourier
+# ----------------------------------------------------------------------------
+class _FSpectral1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, modes: int, mode: int, norm: int):
+        lib = load()
+        x = _f32c(x)
+        wf = _f32c(w) if w is not None else None
+        B, n, Cc = x.shape
+        out = torch.empty_like(x)
+        spec = torch.empty(lib.rpde_fspectral1d_spec_elems(B, n, Cc, modes), dtype=torch.float32, device=x.device)
+        nws = lib.rpde_fspectral1d_ws_bytes(B, n, Cc, modes)
+        ws = workspace(nws, x.device)
+        check(lib.rpde_fspectral1d_fwd(ptr(x), ptr(wf), ptr(out), ptr(spec), B, n, Cc, modes, mode, norm,
+                                       ws.data_ptr(), nws, stream_ptr()), "fspectral1d_fwd")
+        ctx.save_for_backward(spec, wf if wf is not None else x.new_empty(0))
+        ctx.dims = (B, n, Cc, modes, mode, norm, wf is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        spec, wf = ctx.saved_tensors
+        B, n, Cc, modes, mode, norm, has_w = ctx.dims
+        g = _f32c(g)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and has_w
+        gx = torch.empty_like(g) if need_x else None
+        gw = torch.empty_like(wf) if need_w else None
+        nws = lib.rpde_fspectral1d_ws_bytes(B, n, Cc, modes)
+        ws = workspace(nws, g.device)
+        check(lib.rpde_fspectral1d_bwd(ptr(g), ptr(spec), ptr(wf) if has_w else None, ptr(gx), ptr(gw), B, n, Cc, modes,
+                                       mode, norm, ws.data_ptr(), nws, stream_ptr()), "fspectral1d_bwd")
+        return gx, gw, None, None, None
+
+
+class _FSpectral2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wy, wx, modes: int, mode: int):
+        lib = load()
+        x = _f32c(x)
+        has_w = wy is not None
+        wyf = _f32c(wy) if has_w else None
+        wxf = _f32c(wx) if has_w else None
+        B, M, N, Cc = x.shape
+        out = torch.empty_like(x)
+        spec_y = torch.empty(lib.rpde_fspectral2d_spec_elems(B, M, N, Cc, modes, 0), dtype=torch.float32, device=x.device)
+        spec_x = torch.empty(lib.rpde_fspectral2d_spec_elems(B, M, N, Cc, modes, 1), dtype=torch.float32, device=x.device)
+        nws = lib.rpde_fspectral2d_ws_bytes(B, M, N, Cc, modes)
+        ws = workspace(nws, x.device)
+        check(lib.rpde_fspectral2d_fwd(ptr(x), ptr(wyf), ptr(wxf), ptr(out), ptr(spec_y), ptr(spec_x), B, M, N, Cc, modes,
+                                       mode, ws.data_ptr(), nws, stream_ptr()), "fspectral2d_fwd")
+        if has_w:
+            ctx.save_for_backward(spec_y, spec_x, wyf, wxf)
+        else:
+            ctx.save_for_backward(spec_y, spec_x)
+        ctx.dims = (B, M, N, Cc, modes, mode, has_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        B, M, N, Cc, modes, mode, has_w = ctx.dims
+        if has_w:
+            spec_y, spec_x, wyf, wxf = ctx.saved_tensors
+        else:
+            (spec_y, spec_x), wyf, wxf = ctx.saved_tensors, None, None
+        g = _f32c(g)
+        need_x = ctx.needs_input_grad[0]
+        need_w = has_w and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        gx = torch.empty_like(g) if need_x else None
+        gwy = torch.empty_like(wyf) if need_w else None
+        gwx = torch.empty_like(wxf) if need_w else None
+        nws = lib.rpde_fspectral2d_ws_bytes(B, M, N, Cc, modes)
+        ws = workspace(nws, g.device)
+        check(lib.rpde_fspectral2d_bwd(ptr(g), ptr(spec_y), ptr(spec_x), ptr(wyf), ptr(wxf), ptr(gx), ptr(gwy), ptr(gwx),
+                                       B, M, N, Cc, modes, mode, ws.data_ptr(), nws, stream_ptr()), "fspectral2d_bwd")
+        return gx, gwy, gwx, None, None
+
+
+def fspectral1d(x, w, modes: int, mode: str = "full", norm: str = "ortho"):
+    """FSpectralConv1d.forward_fourier: x [B,n,C], w [C,C,K,2]."""
+    if mode not in MODE:
+        raise ValueError(f"Mode {mode} not recognized")
+    return _FSpectral1d.apply(x, w if mode == "full" else None, int(modes), MODE[mode], NORM[norm])
+
+
+def fspectral2d(x, wy, wx, modes: int, mode: str = "full"):
+    """FSpectralConv2d.forward_fourier: x [B,M,N,C], w_y/w_x [C,C,K,2]."""
+    if mode not in MODE:
+        # the reference's 2-D layer has no else branch: both spectra stay zero
+        return torch.zeros_like(x)
+    full = mode == "full"
+    return _FSpectral2d.apply(x, wy if full else None, wx if full else None, int(modes), MODE[mode])
+
+
+# ----------------------------------------------------------------------------
+# FeedForward (+ residual / post-activation glue)
+# ----------------------------------------------------------------------------
+class _FeedForward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, cfg, *params):
+        """cfg = (n_layers, dim, factor, layer_norm, eps, dropout_p, seed, post_act)
+        params = W0, b0, ..., W_{L-1}, b_{L-1} [, gamma, beta]"""
+        lib = load()
+        L, dim, factor, layer_norm, eps, p_drop, seed, post_act = cfg
+        shape = x.shape
+        x2 = _f32c(x).reshape(-1, dim)
+        P = x2.shape[0]
+        res2 = _f32c(residual).reshape(-1, dim) if residual is not None else None
+        ws_ = [_f32c(params[2 * l]) for l in range(L)]
+        bs_ = [_f32c(params[2 * l + 1]) for l in range(L)]
+        gamma = _f32c(params[2 * L]) if layer_norm else None
+        beta = _f32c(params[2 * L + 1]) if layer_norm else None
+        zs = [torch.empty(P, dim if l == L - 1 else dim * factor, dtype=torch.float32, device=x.device) for l in range(L)]
+        out = torch.empty(P, dim, dtype=torch.float32, device=x.device)
+        wa, ba, za = ptr_array(ws_), ptr_array(bs_), ptr_array(zs)
+        fp = _lib.FFParams(L, dim, factor, int(layer_norm), eps, p_drop, seed, post_act,
+                           C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta))
+        check(lib.rpde_feedforward_fwd(C.byref(fp), ptr(x2), ptr(res2), C.cast(za, C.POINTER(C.c_void_p)), ptr(out), P,
+                                       None, 0, stream_ptr()), "feedforward_fwd")
+        ctx.cfg = cfg
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x2, *zs, *ws_, *bs_, *([gamma, beta] if layer_norm else []))
+        return out.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        L, dim, factor, layer_norm, eps, p_drop, seed, post_act = ctx.cfg
+        saved = ctx.saved_tensors
+        x2, zs = saved[0], list(saved[1:1 + L])
+        ws_, bs_ = list(saved[1 + L:1 + 2 * L]), list(saved[1 + 2 * L:1 + 3 * L])
+        gamma, beta = (saved[1 + 3 * L], saved[2 + 3 * L]) if layer_norm else (None, None)
+        P = x2.shape[0]
+        g2 = _f32c(g).reshape(-1, dim)
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gws = [torch.empty_like(w) for w in ws_]
+        gbs = [torch.empty_like(b) for b in bs_]
+        ggamma = torch.empty_like(gamma) if layer_norm else None
+        gbeta = torch.empty_like(beta) if layer_norm else None
+        wa, ba, za = ptr_array(ws_), ptr_array(bs_), ptr_array(zs)
+        gwa, gba = ptr_array(gws), ptr_array(gbs)
+        fp = _lib.FFParams(L, dim, factor, int(layer_norm), eps, p_drop, seed, post_act,
+                           C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta))
+        nws = lib.rpde_feedforward_ws_bytes(P, dim, factor, L)
+        ws = workspace(nws, g.device)
+        check(lib.rpde_feedforward_bwd(C.byref(fp), ptr(x2), C.cast(za, C.POINTER(C.c_void_p)), ptr(g2), ptr(gx),
+                                       C.cast(gwa, C.POINTER(C.c_void_p)), C.cast(gba, C.POINTER(C.c_void_p)),
+                                       ptr(ggamma), ptr(gbeta), P, ws.data_ptr(), nws, stream_ptr()), "feedforward_bwd")
+        grads: List[Optional[torch.Tensor]] = []
+        for l in range(L):
+            grads += [gws[l], gbs[l]]
+        if layer_norm:
+            grads += [ggamma, gbeta]
+        gres = g if ctx.has_res else None
+        return (gx.reshape(g.shape) if gx is not None else None, gres, None, *grads)
+
+
+def feedforward(x, residual, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], ln: Optional[Tuple],
+                dim: int, factor: int, dropout_p: float, seed: int, post_act: str = "identity", eps: float = 1e-5):
+    L = len(weights)
+    params: List[torch.Tensor] = []
+    for w, b in zip(weights, biases):
+        params += [w, b]
+    if ln is not None:
+        params += [ln[0], ln[1]]
+    cfg = (L, int(dim), int(factor), ln is not None, float(eps), float(dropout_p), int(seed) & (2 ** 64 - 1), ACT[post_act])
+    return _FeedForward.apply(x, residual, cfg, *params)
+
+
+# ----------------------------------------------------------------------------
+# pointwise linear (channels-last)
+# ----------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = load()
+        in_f, out_f = w.shape[1], w.shape[0]
+        x2 = _f32c(x).reshape(-1, in_f)
+        w = _f32c(w)
+        b = _f32c(b) if b is not None else None
+        P = x2.shape[0]
+        out = torch.empty(P, out_f, dtype=torch.float32, device=x.device)
+        check(lib.rpde_linear_fwd(ptr(x2), ptr(w), ptr(b), ptr(out), P, in_f, out_f, stream_ptr()), "linear_fwd")
+        ctx.save_for_backward(x2, w)
+        ctx.has_b = b is not None
+        return out.reshape(*x.shape[:-1], out_f)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        x2, w = ctx.saved_tensors
+        out_f, in_f = w.shape
+        P = x2.shape[0]
+        g2 = _f32c(g).reshape(-1, out_f)
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(out_f, dtype=torch.float32, device=g.device) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        nws = lib.rpde_linear_ws_bytes(P, in_f, out_f)
+        ws = workspace(nws, g.device)
+        check(lib.rpde_linear_bwd(ptr(x2), ptr(w), ptr(g2), ptr(gx), ptr(gw), ptr(gb), P, in_f, out_f, ws.data_ptr(), nws,
+                                  stream_ptr()), "linear_bwd")
+        return (gx.reshape(*g.shape[:-1], in_f) if gx is not None else None), gw, gb
+
+
+def linear(x, w, b=None):
+    return _Linear.apply(x, w, b)
+
+
+# ----------------------------------------------------------------------------
+# FNO: channels-first spectral conv, 1x1 conv, activation
+# ----------------------------------------------------------------------------
+class _Spectral1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, act_in: int):
+        lib = load()
+        x = _f32c(x)
+        wf = _as_float_storage(w)
+        B, Ci, n = x.shape
+        Co, K = w.shape[1], w.shape[2]
+        out = torch.empty(B, Co, n, dtype=torch.float32, device=x.device)
+        kp = (K + 3) // 4 * 4
+        spec = torch.empty(B * Ci * 2 * kp, dtype=torch.float32, device=x.device)
+        nws = lib.rpde_spectral1d_ws_bytes(B, Ci, Co, n, K)
+        ws = workspace(nws, x.device)
+        check(lib.rpde_spectral1d_fwd(ptr(x), ptr(wf), ptr(out), ptr(spec), B, Ci, Co, n, K, act_in, ws.data_ptr(), nws,
+                                      stream_ptr()), "spectral1d_fwd")
+        ctx.save_for_backward(spec, w, x if act_in else x.new_empty(0))
+        ctx.dims = (B, Ci, Co, n, K, act_in)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        spec, w, x = ctx.saved_tensors
+        B, Ci, Co, n, K, act_in = ctx.dims
+        g = _f32c(g)
+        wf = _as_float_storage(w)
+        gx = torch.empty(B, Ci, n, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        nws = lib.rpde_spectral1d_ws_bytes(B, Ci, Co, n, K)
+        ws = workspace(nws, g.device)
+        check(lib.rpde_spectral1d_bwd(ptr(g), ptr(spec), ptr(wf), ptr(x) if act_in else None, ptr(gx),
+                                      ptr(_as_float_storage(gw)) if gw is not None else None, B, Ci, Co, n, K, act_in,
+                                      ws.data_ptr(), nws, stream_ptr()), "spectral1d_bwd")
+        return gx, gw, None
+
+
+class _Spectral2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, w2, act_in: int):
+        lib = load()
+        x = _f32c(x)
+        B, Ci, M, N = x.shape
+        Co, m1, m2 = w1.shape[1], w1.shape[2], w1.shape[3]
+        out = torch.empty(B, Co, M, N, dtype=torch.float32, device=x.device)
+        spec = torch.empty(lib.rpde_spectral2d_spec_elems(B, Ci, M, N, m1, m2), dtype=torch.float32, device=x.device)
+        nws = lib.rpde_spectral2d_ws_bytes(B, Ci, Co, M, N, m1, m2)
+        ws = workspace(nws, x.device)
+        check(lib.rpde_spectral2d_fwd(ptr(x), ptr(_as_float_storage(w1)), ptr(_as_float_storage(w2)), ptr(out), ptr(spec),
+                                      B, Ci, Co, M, N, m1, m2, act_in, ws.data_ptr(), nws, stream_ptr()), "spectral2d_fwd")
+        ctx.save_for_backward(spec, w1, w2, x if act_in else x.new_empty(0))
+        ctx.dims = (B, Ci, Co, M, N, m1, m2, act_in)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        spec, w1, w2, x = ctx.saved_tensors
+        B, Ci, Co, M, N, m1, m2, act_in = ctx.dims
+        g = _f32c(g)
+        gx = torch.empty(B, Ci, M, N, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gw1 = torch.empty_like(w1) if need_w else None
+        gw2 = torch.empty_like(w2) if need_w else None
+        nws = lib.rpde_spectral2d_ws_bytes(B, Ci, Co, M, N, m1, m2)
+        ws = workspace(nws, g.device)
+        check(lib.rpde_spectral2d_bwd(ptr(g), ptr(spec), ptr(_as_float_storage(w1)), ptr(_as_float_storage(w2)),
+                                      ptr(x) if act_in else None, ptr(gx),
+                                      ptr(_as_float_storage(gw1)) if need_w else None,
+                                      ptr(_as_float_storage(gw2)) if need_w else None,
+                                      B, Ci, Co, M, N, m1, m2, act_in, ws.data_ptr(), nws, stream_ptr()), "spectral2d_bwd")
+        return gx, gw1, gw2, None
+
+
+def spectral1d(x, w, act_in: str = "identity"):
+    if w.shape[2] > x.shape[-1] // 2 + 1:
+        raise RuntimeError(f"SpectralConv1d: modes1={w.shape[2]} exceeds n//2+1={x.shape[-1] // 2 + 1}")
+    return _Spectral1d.apply(x, w, ACT[act_in])
+
+
+def spectral2d(x, w1, w2, act_in: str = "identity"):
+    if w1.shape[3] > x.shape[-1] // 2 + 1 or w1.shape[2] > x.shape[-2]:
+        raise RuntimeError("SpectralConv2d: modes exceed the available spectrum")
+    return _Spectral2d.apply(x, w1, w2, ACT[act_in])
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act_in: int, acc):
+        """out = (acc +) W . act(x) + b ; x [B,Cin,*S] channels-first, w [Cout,Cin,1(,1)]"""
+        lib = load()
+        x = _f32c(x)
+        B, Ci = x.shape[0], x.shape[1]
+        S = x[0, 0].numel()
+        Co = w.shape[0]
+        w2 = _f32c(w).reshape(Co, Ci)
+        b = _f32c(b) if b is not None else None
+        if acc is not None:
+            if acc.dtype == torch.float32 and acc.is_contiguous() and not acc.is_leaf:
+                ctx.mark_dirty(acc)          # accumulate in place into the spectral branch's output
+                out = acc
+            else:
+                out = _f32c(acc).clone()
+        else:
+            out = torch.empty(B, Co, *x.shape[2:], dtype=torch.float32, device=x.device)
+        check(lib.rpde_conv1x1_fwd(ptr(x), ptr(w2), ptr(b), ptr(out), B, Ci, Co, S, act_in, int(acc is not None),
+                                   stream_ptr()), "conv1x1_fwd")
+        ctx.save_for_backward(x, w2)
+        ctx.meta = (B, Ci, Co, S, act_in, b is not None, acc is not None, w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        x, w2 = ctx.saved_tensors
+        B, Ci, Co, S, act_in, has_b, has_acc, wshape = ctx.meta
+        g = _f32c(g)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w2) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(Co, dtype=torch.float32, device=g.device) if (has_b and ctx.needs_input_grad[2]) else None
+        nws = lib.rpde_conv1x1_ws_bytes(B, Ci, Co, S)
+        ws = workspace(nws, g.device)
+        check(lib.rpde_conv1x1_bwd(ptr(x), ptr(w2), ptr(g), ptr(gx), ptr(gw), ptr(gb), B, Ci, Co, S, act_in, 0,
+                                   ws.data_ptr(), nws, stream_ptr()), "conv1x1_bwd")
+        return gx, (gw.reshape(wshape) if gw is not None else None), gb, None, (g if has_acc else None)
+
+
+def conv1x1(x, w, b=None, act_in: str = "identity", acc=None):
+    return _Conv1x1.apply(x, w, b, ACT[act_in], acc)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act: int):
+        lib = load()
+        x = _f32c(x)
+        out = torch.empty_like(x)
+        check(lib.rpde_act_fwd(ptr(x), ptr(out), x.numel(), act, stream_ptr()), "act_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        (x,) = ctx.saved_tensors
+        g = _f32c(g)
+        dx = torch.empty_like(x)
+        check(lib.rpde_act_bwd(ptr(x), ptr(g), ptr(dx), x.numel(), ctx.act, stream_ptr()), "act_bwd")
+        return dx, None
+
+
+def activation(x, act: str):
+    return x if act == "identity" else _Act.apply(x, ACT[act])
+
+
+# ----------------------------------------------------------------------------
+# model-boundary layout helpers
+# ----------------------------------------------------------------------------
+class _ConcatGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, grid_dims: int, lo: float, hi: float, channels_last: bool, gx, gy):
+        lib = load()
+        x = _f32c(x)
+        B, Ci = x.shape[0], x.shape[1]
+        sp = tuple(x.shape[2:])
+        M, N = (sp[0], 1) if len(sp) == 1 else sp
+        Ct = Ci + grid_dims
+        shape = (B, *sp, Ct) if channels_last else (B, Ct, *sp)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        check(lib.rpde_concat_grid(ptr(x), ptr(out), B, Ci, M, N, grid_dims, lo, hi, int(channels_last),
+                                   ptr(gx), ptr(gy), stream_ptr()), "concat_grid")
+        ctx.meta = (Ci, channels_last, len(sp))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Ci, channels_last, nd = ctx.meta
+        if channels_last:
+            gx = g[..., :Ci]
+            gx = gx.permute(0, nd + 1, *range(1, nd + 1))
+        else:
+            gx = g[:, :Ci]
+        return gx.contiguous(), None, None, None, None, None, None
+
+
+def concat_grid(x, grid_dims: int, lo: float = 0.0, hi: float = 1.0, channels_last: bool = True, gridx=None, gridy=None):
+    return _ConcatGrid.apply(x, grid_dims, float(lo), float(hi), bool(channels_last), gridx, gridy)
+
+
+class _TransposeCS(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, to_channels_first: bool):
+        """to_channels_first: [B,*S,C] -> [B,C,*S];  else the inverse"""
+        lib = load()
+        x = _f32c(x)
+        B = x.shape[0]
+        if to_channels_first:
+            sp, Cc = tuple(x.shape[1:-1]), x.shape[-1]
+            out = torch.empty(B, Cc, *sp, dtype=torch.float32, device=x.device)
+        else:
+            Cc, sp = x.shape[1], tuple(x.shape[2:])
+            out = torch.empty(B, *sp, Cc, dtype=torch.float32, device=x.device)
+        S = 1
+        for s in sp:
+            S *= s
+        check(lib.rpde_transpose_cs(ptr(x), ptr(out), B, S, Cc, int(to_channels_first), stream_ptr()), "transpose_cs")
+        ctx.tcf = to_channels_first
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _TransposeCS.apply(g, not ctx.tcf), None
+
+
+def to_channels_first(x):
+    if x.shape[-1] == 1:
+        return x.reshape(x.shape[0], 1, *x.shape[1:-1])
+    return _TransposeCS.apply(x, True)
+
+
+def to_channels_last(x):
+    if x.shape[1] == 1:
+        return x.reshape(x.shape[0], *x.shape[2:], 1)
+    return _TransposeCS.apply(x, False)
+
+
+# ----------------------------------------------------------------------------
+# relative L2 loss
+# ----------------------------------------------------------------------------
+class _RelL2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, size_average: bool, reduction: bool):
+        lib = load()
+        x = _f32c(x)
+        y = _f32c(y)
+        B = x.shape[0]
+        per = x.numel() // B
+        if y.numel() != x.numel():
+            raise RuntimeError(f"RelativeL2Loss: shapes {tuple(x.shape)} and {tuple(y.shape)} differ in size")
+        stats = torch.empty(lib.rpde_rel_l2_stats_elems(B), dtype=torch.float32, device=x.device)
+        rel = torch.empty(B, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device) if reduction else None
+        check(lib.rpde_rel_l2_fwd(ptr(x), ptr(y), ptr(rel), ptr(loss), ptr(stats), B, per, int(size_average),
+                                  stream_ptr()), "rel_l2_fwd")
+        ctx.save_for_backward(x, y, stats)
+        ctx.meta = (B, per, size_average, reduction)
+        return loss if reduction else rel
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        x, y, stats = ctx.saved_tensors
+        B, per, size_average, reduction = ctx.meta
+        g = _f32c(g)
+        gx = torch.empty_like(x)
+        check(lib.rpde_rel_l2_bwd(ptr(x), ptr(y), ptr(stats), ptr(g) if reduction else None,
+                                  None if reduction else ptr(g), ptr(gx), B, per, int(size_average), stream_ptr()),
+              "rel_l2_bwd")
+        return gx, None, None, None
+
+
+def relative_l2(x, y, size_average: bool = True, reduction: bool = True):
+    return _RelL2.apply(x, y, bool(size_average), bool(reduction))

@@ -1,0 +1,169 @@
+"""GPU: kernel-level checks of librpde_hip.so through its C ABI.
+
+The GEMM is compared with a float64 torch matmul of the same operands (a plain
+torch reference is right for a floating-point kernel); the DFT plan tables with
+the float64 restatement in oracle/dft_math.py; the dropout masks of the three
+places that regenerate them with each other."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GEMM_TOL = 2e-6     # fp32 MFMA (exact fp32 FMA chain) vs float64, rel-L2
+
+
+def _gemm(dev, M, N, K, a_k, b_k, batch=1, ksplit=1, bias_mode=0, accumulate=False, act_a=0, act_b=0, seed=0,
+          alpha=1.0, write_act=0):
+    from rpde import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = torch.randn(batch, M, K, generator=g)
+    B = torch.randn(batch, K, N, generator=g)
+    Ad = (A if a_k else A.transpose(1, 2)).contiguous().to(dev)      # [b,M,K] or [b,K,M]
+    Bd = (B.transpose(1, 2) if b_k else B).contiguous().to(dev)      # [b,N,K] or [b,K,N]
+    C0 = torch.randn(batch, M, N, generator=g)
+    Cd = C0.clone().to(dev) if ksplit == 1 else torch.zeros(ksplit, batch, M, N, device=dev)
+    bias = torch.randn(N if bias_mode == 1 else M, generator=g)
+    bd = bias.to(dev)
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.a_kmajor, d.b_kmajor = int(a_k), int(b_k)
+    d.lda = K if a_k else M
+    d.ldb = K if b_k else N
+    d.ldc = N
+    d.batch, d.zdiv = batch, 1
+    d.sA1, d.sB1, d.sC1 = M * K, K * N, M * N
+    d.ksplit, d.sCk = ksplit, batch * M * N
+    d.alpha, d.accumulate = alpha, int(accumulate)
+    if bias_mode:
+        d.bias, d.bias_mode = bd.data_ptr(), bias_mode
+    d.act_a, d.act_b, d.write_act = act_a, act_b, write_act
+    _lib.check(lib.rpde_gemm_f32(C.byref(d), _lib.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    act = {0: lambda t: t, 1: torch.nn.functional.gelu, 2: torch.relu}
+    ref = alpha * (act[act_a](A.double()) @ act[act_b](B.double()))
+    if bias_mode == 1:
+        ref = ref + bias.double()[None, None, :]
+    elif bias_mode == 2:
+        ref = ref + bias.double()[None, :, None]
+    if accumulate:
+        ref = ref + C0.double()
+    ref = act[write_act](ref)
+    got = Cd.cpu().double() if ksplit == 1 else Cd.cpu().double().sum(0)
+    return float((got - ref).norm() / ref.norm())
+
+
+LAYOUTS = [(1, 1), (1, 0), (0, 0), (0, 1)]
+SHAPES = [(128, 128, 64), (256, 256, 256), (200, 72, 40), (33, 17, 5), (40, 64, 256), (64, 3, 7), (1000, 64, 3),
+          (512, 1, 64), (31, 129, 130), (129, 31, 33), (300, 40, 36)]
+
+
+@pytest.mark.parametrize("a_k,b_k", LAYOUTS)
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_layouts_and_edges(gpu_device, M, N, K, a_k, b_k):
+    err = _gemm(gpu_device, M, N, K, a_k, b_k, seed=M + N + K)
+    assert err < GEMM_TOL, err
+
+
+def test_gemm_batched_bias_accumulate(gpu_device):
+    assert _gemm(gpu_device, 130, 70, 50, 1, 0, batch=5, bias_mode=1, accumulate=True) < GEMM_TOL
+    assert _gemm(gpu_device, 64, 200, 33, 1, 0, batch=3, bias_mode=2, alpha=0.5) < GEMM_TOL
+
+
+def test_gemm_split_k(gpu_device):
+    assert _gemm(gpu_device, 256, 256, 5000, 0, 0, ksplit=7) < 4e-6
+    assert _gemm(gpu_device, 64, 3, 4097, 0, 0, ksplit=16, batch=2) < 4e-6
+
+
+def test_gemm_activation_prologue_and_store(gpu_device):
+    assert _gemm(gpu_device, 200, 256, 64, 1, 1, act_a=1) < 1e-5
+    assert _gemm(gpu_device, 128, 100, 300, 0, 0, act_b=1) < 1e-5
+    assert _gemm(gpu_device, 77, 130, 40, 1, 0, act_b=2, write_act=2) < 1e-5
+
+
+def test_gemm_dact_epilogue_matches_autograd(gpu_device):
+    """C = (G @ W) * gelu'(Z) against torch autograd of gelu."""
+    from rpde import _lib
+    lib = _lib.load()
+    P, N, K = 300, 96, 64
+    g = torch.Generator().manual_seed(3)
+    G, W, Z = torch.randn(P, K, generator=g), torch.randn(K, N, generator=g), torch.randn(P, N, generator=g)
+    Gd, Wd, Zd = G.to(gpu_device), W.to(gpu_device), Z.to(gpu_device)
+    out = torch.empty(P, N, device=gpu_device)
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = Gd.data_ptr(), Wd.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = P, N, K, 1, 0
+    d.lda, d.ldb, d.ldc, d.batch, d.zdiv, d.ksplit, d.alpha = K, N, N, 1, 1, 1, 1.0
+    d.epi_dact, d.aux, d.ldaux = 1, Zd.data_ptr(), N
+    _lib.check(lib.rpde_gemm_f32(C.byref(d), _lib.stream_ptr()), "gemm")
+    z = Z.double().requires_grad_(True)
+    torch.nn.functional.gelu(z).backward(G.double() @ W.double())
+    err = float((out.cpu().double() - z.grad).norm() / z.grad.norm())
+    assert err < 1e-5, err
+
+
+def test_dropout_masks_agree_between_prologues_and_epilogue(gpu_device):
+    """The forward staging (A operand), the weight-gradient staging (B operand)
+    and the backward-data epilogue must regenerate one and the same mask."""
+    from rpde import _lib
+    lib = _lib.load()
+    P, J, p, seed = 256, 128, 0.25, 1234567
+    eye_j = torch.eye(J, device=gpu_device)
+    eye_p = torch.eye(P, device=gpu_device)
+    ones = torch.ones(P, J, device=gpu_device)
+
+    def run(**kw):
+        out = torch.empty(P, J, device=gpu_device)
+        d = _lib.GemmDesc()
+        d.batch, d.zdiv, d.ksplit, d.alpha = 1, 1, 1, 1.0
+        d.C, d.ldc, d.M, d.N = out.data_ptr(), J, P, J
+        d.drop_p, d.drop_seed, d.drop_ld = p, seed, J
+        for k, v in kw.items():
+            setattr(d, k, v)
+        _lib.check(lib.rpde_gemm_f32(C.byref(d), _lib.stream_ptr()), "gemm")
+        return out.cpu()
+
+    # A-operand prologue: identity act + dropout of ones, times I
+    m_a = run(A=ones.data_ptr(), lda=J, a_kmajor=1, B=eye_j.data_ptr(), ldb=J, b_kmajor=0, K=J, act_a=0)
+    # B-operand prologue: I[P,P] times dropout(ones[P,J]) with points along the reduction
+    m_b = run(A=eye_p.data_ptr(), lda=P, a_kmajor=1, B=ones.data_ptr(), ldb=J, b_kmajor=0, K=P, act_b=0)
+    # epilogue: acc = ones, aux large so gelu'(aux*s) is 1 where kept
+    big = torch.full((P, J), 30.0, device=gpu_device)
+    m_e = run(A=ones.data_ptr(), lda=J, a_kmajor=1, B=eye_j.data_ptr(), ldb=J, b_kmajor=0, K=J, epi_dact=1,
+              aux=big.data_ptr(), ldaux=J, drop_p=p)
+    # the A prologue scaled the operand AND the epilogue scaled again -> compare supports
+    keep_a, keep_b, keep_e = m_a != 0, m_b != 0, m_e != 0
+    assert torch.equal(keep_a, keep_b) and torch.equal(keep_a, keep_e)
+    frac = 1.0 - keep_a.float().mean().item()
+    assert abs(frac - p) < 0.02, frac
+    scale = m_b[keep_b].unique()
+    assert scale.numel() == 1 and abs(scale.item() - 1 / (1 - p)) < 1e-3
+
+
+@pytest.mark.parametrize("n,k,norm", [(256, 20, "ortho"), (33, 17, "backward"), (64, 33, "ortho"), (1024, 16, "backward")])
+def test_plan_tables_match_float64_restatement(gpu_device, n, k, norm):
+    from oracle import dft_math as D
+    from rpde import _lib
+    lib = _lib.load()
+    plan = C.c_void_p()
+    _lib.check(lib.rpde_plan_create(C.byref(plan), n, k, _lib.NORM[norm], _lib.stream_ptr()), "plan_create")
+    nn_, mm, kp, ldn = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _lib.check(lib.rpde_plan_info(plan, C.byref(nn_), C.byref(mm), C.byref(kp), C.byref(ldn)), "plan_info")
+    fa = np.zeros((2 * kp.value, ldn.value), dtype=np.float32)
+    fs = np.zeros((n, 2 * kp.value), dtype=np.float32)
+    _lib.check(lib.rpde_plan_tables(plan, fa.ctypes.data, fs.ctypes.data), "plan_tables")
+    _lib.check(lib.rpde_plan_destroy(plan), "plan_destroy")
+    ra, rs = D.analysis(n, k, norm), D.synthesis(n, k, norm)
+    assert np.abs(fa[:2 * k, :n] - ra).max() <= 6e-8 * max(1.0, np.abs(ra).max())
+    assert np.abs(fs[:, :2 * k] - rs).max() <= 6e-8 * max(1.0, np.abs(rs).max())
+    assert not fa[2 * k:].any() and not fa[:, n:].any() and not fs[:, 2 * k:].any()
+
+
+def test_cpu_tensor_is_rejected_loudly(gpu_device):
+    from rpde import RpdeError, ops
+    with pytest.raises(RpdeError):
+        ops.relative_l2(torch.randn(2, 8), torch.randn(2, 8))
