@@ -81,9 +81,11 @@ typedef struct {
   /* epilogue: C = acc * act'(drop(aux)) * dropscale   (backward through act)      */
   int epi_dact;            /* RPDE_ACT_* or 0                                       */
   const float* aux; int64_t ldaux;
-  /* dropout shared by prologue / epilogue: element id = point*drop_ld + feature    */
+  /* dropout shared by prologue / epilogue: element id = point*drop_ld + feature;
+   * drop_where: bit 0 mask the A operand, bit 1 the B operand, bit 2 the epilogue's aux */
   float drop_p; uint64_t drop_seed; int64_t drop_ld;
   int write_act;           /* epilogue applies act (RPDE_ACT_*) to the stored value */
+  int drop_where;
 } rpde_gemm_desc;
 int rpde_gemm_f32(const rpde_gemm_desc* d, void* stream);
 

@@ -39,7 +39,7 @@ static int linear_fwd_impl(const float* x, const float* w, const float* b, float
   d.C = y; d.ldc = out_f;
   d.M = (int)P; d.N = out_f; d.K = in_f;
   d.bias = b; d.bias_mode = b ? 1 : 0;
-  d.act_a = act_in; d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f;
+  d.act_a = act_in; d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f; d.drop_where = 1;
   return launch_gemm(d, st);
 }
 
@@ -52,7 +52,7 @@ static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* 
     d.A = gy; d.a_kmajor = 0; d.lda = out_f;
     d.B = x; d.b_kmajor = 0; d.ldb = in_f;
     d.M = out_f; d.N = in_f; d.K = (int)P;
-    d.act_b = act_in; d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f;
+    d.act_b = act_in; d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f; d.drop_where = 2;
     if (S > 1) {
       d.C = ws_slabs; d.ldc = in_f; d.ksplit = S; d.sCk = (long)out_f * in_f;
       RPDE_TRY(launch_gemm(d, st));
@@ -75,7 +75,7 @@ static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P,
   d.C = gx; d.ldc = in_f;
   d.M = (int)P; d.N = in_f; d.K = out_f;
   d.epi_dact = epi_dact; d.aux = z; d.ldaux = in_f;
-  d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f;
+  d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f; d.drop_where = 4;
   return launch_gemm(d, st);
 }
 

@@ -48,7 +48,7 @@ struct GemmK {
   const float* bias; int bias_mode;
   int act_a, act_b, epi_dact, write_act;
   const float* aux; long ldaux;
-  DropCfg drop; long drop_ld;
+  DropCfg drop; long drop_ld; int drop_where;
   int a_vec, b_vec;
   int mtiles, ntiles;
 };
@@ -103,15 +103,15 @@ struct Tile {
 
   // registers -> LDS, applying h = act(dropout(z)) when requested
   __device__ __forceinline__ static void store(float* __restrict__ lds, const float4 (&r)[NV], int tid, int act,
-                                               const DropCfg& drop, long drop_ld, int r0, int k0) {
+                                               bool use_drop, const DropCfg& drop, long drop_ld, int r0, int k0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int rr, kk;
       coords(tid + i * NTHREADS, rr, kk);
       float4 v = r[i];
-      if (act != RPDE_ACT_IDENTITY || drop.on()) {
+      if (act != RPDE_ACT_IDENTITY || use_drop) {
         float s[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop.on()) {
+        if (use_drop) {
           const long slow = KMAJOR ? (long)(r0 + rr) : (long)(k0 + kk);
           const long fast = KMAJOR ? (long)(k0 + kk) : (long)(r0 + rr);
           const uint64_t id = (uint64_t)(slow * drop_ld + fast);
@@ -187,12 +187,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool drop_a = g.drop.on() && (g.drop_where & 1);
+  const bool drop_b = g.drop.on() && (g.drop_where & 2);
+  const bool drop_e = g.drop.on() && (g.drop_where & 4);
   float4 ra[TA::NV], rb[TB::NV];
   if (nkt > 0) {
     TA::load(ra, A, g.lda, m0, g.M, kbeg, kend, g.a_vec, tid);
     TB::load(rb, B, g.ldb, n0, g.N, kbeg, kend, g.b_vec, tid);
-    TA::store(As0, ra, tid, g.act_a, g.drop, g.drop_ld, m0, kbeg);
-    TB::store(Bs0, rb, tid, g.act_b, g.drop, g.drop_ld, n0, kbeg);
+    TA::store(As0, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, kbeg);
+    TB::store(Bs0, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, kbeg);
   }
   __syncthreads();
 
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      TA::store((kt & 1) ? As0 : As1, ra, tid, g.act_a, g.drop, g.drop_ld, m0, knext);
-      TB::store((kt & 1) ? Bs0 : Bs1, rb, tid, g.act_b, g.drop, g.drop_ld, n0, knext);
+      TA::store((kt & 1) ? As0 : As1, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);
+      TB::store((kt & 1) ? Bs0 : Bs1, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext);
     }
     __syncthreads();
   }
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
         else if (g.bias_mode == 2) v += g.bias[m];
         if (g.epi_dact) {
           float s = 1.f;
-          if (g.drop.on()) s = drop_scale1(g.drop, (uint64_t)((long)m * g.drop_ld + n));
+          if (drop_e) s = drop_scale1(g.drop, (uint64_t)((long)m * g.drop_ld + n));
           const float u = aux[(long)m * g.ldaux + n] * s;
           v = v * dact_f(g.epi_dact, u) * s;
         }
@@ -292,7 +295,7 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   g.bias = d.bias; g.bias_mode = d.bias ? d.bias_mode : 0;
   g.act_a = d.act_a; g.act_b = d.act_b; g.epi_dact = d.epi_dact; g.write_act = d.write_act;
   g.aux = d.aux; g.ldaux = d.ldaux;
-  g.drop = make_drop(d.drop_p, d.drop_seed); g.drop_ld = d.drop_ld;
+  g.drop = make_drop(d.drop_p, d.drop_seed); g.drop_ld = d.drop_ld; g.drop_where = d.drop_where;
   // 16-byte vector loads need aligned bases, strides and leading dims
   g.a_vec = al16(d.A) && (d.lda % 4 == 0) && (d.sA1 % 4 == 0) && (d.sA2 % 4 == 0);
   g.b_vec = al16(d.B) && (d.ldb % 4 == 0) && (d.sB1 % 4 == 0) && (d.sB2 % 4 == 0);

@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
         ("epi_dact", C.c_int),
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64),
-        ("write_act", C.c_int),
+        ("write_act", C.c_int), ("drop_where", C.c_int),
     ]
 
 

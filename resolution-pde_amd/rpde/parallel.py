@@ -1,0 +1,59 @@
+"""Data-parallel gradient exchange: one process per GPU, one flat fp32 bucket,
+one all-reduce per step (torch.distributed 'nccl' = RCCL over xGMI on ROCm;
+'gloo' in the CPU tests).
+
+Every op of the hot path is per-sample; the only cross-sample coupling is the
+batch mean of the loss, so ranks own disjoint samples and exchange nothing but
+the gradient sum (6.8 MB for FFNO2D-m20-w64).  The parameters' ``.grad`` are
+views into the bucket, so there is no pack / unpack copy around the
+collective.  The reference's only multi-GPU mode is single-process
+nn.DataParallel (main_2d.py:147-149); this is its one-process-per-GPU
+counterpart with the same semantics for equal local batches (mean over the
+concatenated batch).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        sizes = [p.numel() * (2 if p.is_complex() else 1) for p in self.params]
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        off = 0
+        for p, n in zip(self.params, sizes):
+            chunk = self.flat[off:off + n]
+            if p.is_complex():
+                p.grad = torch.view_as_complex(chunk.view(*p.shape, 2))
+            else:
+                if p.dtype != torch.float32:
+                    raise TypeError(f"expected fp32 / complex64 parameters, got {p.dtype}")
+                p.grad = chunk.view(p.shape)
+            off += n
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4
+
+    def zero(self) -> None:
+        """replaces optimizer.zero_grad(): keeps the .grad views alive"""
+        self.flat.zero_()
+
+    def all_reduce_mean(self) -> None:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / dist.get_world_size())
+
+
+def shard_indices(n_items: int, world: int, rank: int) -> range:
+    """contiguous, equal-sized shard of [0, n_items) (tail dropped so that all
+    ranks run the same number of identical-shape steps)"""
+    per = n_items // world
+    return range(rank * per, (rank + 1) * per)

@@ -70,8 +70,15 @@ CASES = [
     dict(name="wnlinear_plain", kind="WNLinear", ctor=dict(in_features=64, out_features=1, wnorm=False),
          x=(2, 8, 8, 64), seed=462),
     # ---- G5 whole models ---------------------------------------------------
+    # default activation is ReLU: at this size some pre-activation lies within fp32 noise of the
+    # kink, so the reference's own fp32 and fp64 gradients differ (one sign flip = 3.7e-3 on dx);
+    # the fixture records that floor (``floor=True``) and the check allows 3x it.
     dict(name="fno1d_cfg1", kind="FNO1d", ctor=dict(in_channels=1, out_channels=1, modes=16, width=64),
-         x=(16, 1, 1024), seed=501),
+         x=(16, 1, 1024), seed=501, floor=True),
+    dict(name="fno1d_cfg1_gelu", kind="FNO1d", ctor=dict(in_channels=1, out_channels=1, modes=16, width=64),
+         x=(16, 1, 1024), seed=504, act="gelu"),
+    dict(name="fno1d_small_relu", kind="FNO1d", ctor=dict(in_channels=2, out_channels=1, modes=5, width=8, n_blocks=2),
+         x=(2, 2, 48), seed=505),
     dict(name="ffno1d_cfg2", kind="FFNO1D", ctor=FFNO1D_YAML, x=(4, 1, 512), seed=502),
     dict(name="ffno1d_small_grid", kind="FFNO1D",
          ctor=dict(in_channels=2, out_channels=1, width=16, n_layers=2, n_modes=6, factor=2, ff_weight_norm=False,

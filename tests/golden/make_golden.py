@@ -55,6 +55,21 @@ def main(argv):
 
     torch.set_num_threads(8)
     backend = ModuleBackend(ns, "cpu")
+
+    class Float64Backend(ModuleBackend):
+        """same reference modules with every parameter and input promoted to
+        float64 / complex128 (``.double()`` leaves complex weights alone, quirk Q17)"""
+
+        def make(self, case, sd):
+            inst = super().make(case, sd)
+            mod = inst.module.double()
+            for p_ in mod.parameters():
+                if p_.is_complex():
+                    p_.data = p_.data.to(torch.complex128)
+            inner = inst.call
+            inst.call = lambda x: inner(x.double())
+            inst.leaves = dict(mod.named_parameters())
+            return inst
     want = set(argv)
     for case in CASES:
         if want and case["name"] not in want:
@@ -63,11 +78,20 @@ def main(argv):
         spec = {} if case["kind"] == "RelativeL2Loss" else backend.spec(case)
         sd = synth.fill_state_dict(spec, case["seed"])
         res = run_case(case, backend, sd)
+        floors = {}
+        if case.get("floor"):
+            # the reference's own fp32-vs-fp64 disagreement per result tensor
+            res64 = run_case(case, Float64Backend(ns, "cpu"), sd)
+            for name, t in res.items():
+                r64 = res64[name].to(torch.float64)
+                floors[name] = float((t.to(torch.float64) - r64).norm() / (r64.norm() + 1e-300))
         blob = {"meta": np.array(json.dumps({"case": case, "spec": spec,
                                              "torch": torch.__version__}))}
         for name, t in res.items():
             for k, v in synth.digest(t).items():
                 blob[f"{name}|{k}"] = v
+            if name in floors:
+                blob[f"{name}|floor"] = np.array(floors[name])
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(path, **blob)
         print(f"{case['name']:28s} {len(res):3d} tensors  {os.path.getsize(path) / 1024:8.1f} KiB"

@@ -31,11 +31,19 @@ class ModuleBackend:
     def __init__(self, ns, device: str = "cpu"):
         self.ns, self.device = ns, device
 
+    @staticmethod
+    def ctor(case) -> Dict:
+        c = dict(case["ctor"])
+        if "act" in case:           # activation callables are not JSON data: named in the case
+            import torch.nn.functional as F
+            c["activation"] = {"gelu": F.gelu, "relu": F.relu}[case["act"]]
+        return c
+
     def spec(self, case) -> Dict:
         kind = case.get("model", case["kind"])
         if kind == "Rollout1d":
             kind = "FFNO1D"
-        return synth.spec_of(getattr(self.ns, kind)(**case["ctor"]).state_dict())
+        return synth.spec_of(getattr(self.ns, kind)(**self.ctor(case)).state_dict())
 
     def make(self, case, sd: Mapping[str, torch.Tensor]) -> Instance:
         kind = case.get("model", case["kind"])
@@ -44,7 +52,7 @@ class ModuleBackend:
         if kind == "RelativeL2Loss":
             mod = self.ns.RelativeL2Loss(**case["ctor"])
             return Instance({}, None, mod)
-        mod = getattr(self.ns, kind)(**case["ctor"])
+        mod = getattr(self.ns, kind)(**self.ctor(case))
         got = synth.spec_of(mod.state_dict())
         want = synth.spec_of(sd)
         assert got == want, f"state_dict layout differs for {case['name']}:\n{got}\n{want}"
@@ -99,9 +107,9 @@ class OracleBackend:
         elif kind == "WNLinear":
             call = lambda x: R.wn_linear(x, p, "")
         elif kind == "FNO1d":
-            call = lambda x: R.fno1d_forward(p, x, c.get("n_blocks", 4))
+            call = lambda x: R.fno1d_forward(p, x, c.get("n_blocks", 4), case.get("act", "relu"))
         elif kind == "FNO2d":
-            call = lambda x: R.fno2d_forward(p, x, c.get("n_blocks", 4))
+            call = lambda x: R.fno2d_forward(p, x, c.get("n_blocks", 4), case.get("act", "gelu"))
         elif kind in ("FFNO1D", "Rollout1d"):
             call = lambda x: R.ffno1d_forward(
                 p, x, c.get("n_layers", 4), c.get("n_modes", 16), c.get("n_ff_layers", 2),

@@ -139,6 +139,8 @@ def check_results(res: Mapping[str, torch.Tensor], digests: Mapping[str, Mapping
             continue
         e = compare(t, digests[k])
         lim = grad_tol if (k in gkeys or k.startswith("param/")) else tol
+        if "floor" in digests[k]:      # the reference's own fp32-vs-fp64 disagreement (ReLU kinks)
+            lim = max(lim, 3.0 * float(digests[k]["floor"]))
         assert e <= lim, f"{label}:{k} rel-L2 {e:.3e} > {lim:.1e}"
         errs[k] = e
     return errs

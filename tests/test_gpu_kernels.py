@@ -128,14 +128,13 @@ def test_dropout_masks_agree_between_prologues_and_epilogue(gpu_device):
         return out.cpu()
 
     # A-operand prologue: identity act + dropout of ones, times I
-    m_a = run(A=ones.data_ptr(), lda=J, a_kmajor=1, B=eye_j.data_ptr(), ldb=J, b_kmajor=0, K=J, act_a=0)
+    m_a = run(A=ones.data_ptr(), lda=J, a_kmajor=1, B=eye_j.data_ptr(), ldb=J, b_kmajor=0, K=J, act_a=0, drop_where=1)
     # B-operand prologue: I[P,P] times dropout(ones[P,J]) with points along the reduction
-    m_b = run(A=eye_p.data_ptr(), lda=P, a_kmajor=1, B=ones.data_ptr(), ldb=J, b_kmajor=0, K=P, act_b=0)
+    m_b = run(A=eye_p.data_ptr(), lda=P, a_kmajor=1, B=ones.data_ptr(), ldb=J, b_kmajor=0, K=P, act_b=0, drop_where=2)
     # epilogue: acc = ones, aux large so gelu'(aux*s) is 1 where kept
     big = torch.full((P, J), 30.0, device=gpu_device)
     m_e = run(A=ones.data_ptr(), lda=J, a_kmajor=1, B=eye_j.data_ptr(), ldb=J, b_kmajor=0, K=J, epi_dact=1,
-              aux=big.data_ptr(), ldaux=J, drop_p=p)
-    # the A prologue scaled the operand AND the epilogue scaled again -> compare supports
+              aux=big.data_ptr(), ldaux=J, drop_where=4)
     keep_a, keep_b, keep_e = m_a != 0, m_b != 0, m_e != 0
     assert torch.equal(keep_a, keep_b) and torch.equal(keep_a, keep_e)
     frac = 1.0 - keep_a.float().mean().item()
