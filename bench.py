@@ -104,13 +104,25 @@ def time_spectral(B, device, iters=10):
     return ms, alg_bytes / (ms * 1e-3) / 1e9, alg_bytes
 
 
+def host_cores() -> int:
+    """cores this process may really use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("RPDE_CPU_THREADS", "64"))))
+
+
 def cpu_baseline(batch=2, warm=1, timed=2):
     """the CPU oracle (pinned restatement of the reference) doing the same training step"""
     from models.ffno import FFNO2D
     from oracle import reference_path as R
     torch.manual_seed(0)
     sd = {k: v.clone() for k, v in FFNO2D(**CFG3).state_dict().items()}
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     params = R.make_params(sd)
     opt = torch.optim.AdamW(list(params.values()), lr=1e-3)
@@ -140,6 +152,14 @@ def parity_check(device):
         ref = R.ffno2d_forward(sd, x, cfg["n_layers"], cfg["n_modes"], cfg["n_ff_layers"], cfg["layer_norm"])
         got = model.to(device).eval()(x.to(device)).cpu()
     return float((got - ref).norm() / ref.norm())
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -184,8 +204,11 @@ def main():
         opt.step()
         loss_sum.add_(loss.detach())           # device-side accumulation, no per-step host sync
 
-    for _ in range(args.warmup):
+    log(f"model + data ready (B={B}/gpu, world={world})")
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
     first_loss = None
     if world > 1:
         dist.barrier()
@@ -202,12 +225,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     mean_loss = float(loss_sum.item()) / max(1, args.steps + args.warmup)
+    log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
         g_ms, g_tf, g_flops = time_ff_gemm(B, device)
+        log(f"FF GEMM {g_ms:.3f} ms = {g_tf:.1f} TF")
         s_ms, s_gbs, s_bytes = time_spectral(B, device)
+        log(f"spectral fwd {s_ms:.3f} ms = {s_gbs:.0f} GB/s algorithmic")
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -236,8 +262,10 @@ def main():
         }
         if world == 1:
             line["parity"] = {"fwd_rel_l2_vs_cpu_oracle": parity_check(device), "tolerance": 1e-5}
+            log(f"parity {line['parity']}")
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
+                log(f"cpu baseline {line['cpu_baseline']['value']} samples/s")
                 line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:

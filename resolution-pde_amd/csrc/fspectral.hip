@@ -30,7 +30,7 @@ struct Axis {
 };
 
 static inline int split_for(long k_total, int tiles) {
-  long s = 768 / (tiles > 0 ? tiles : 1);
+  long s = 512 / (tiles > 0 ? tiles : 1);
   const long cap = (k_total + 127) / 128;
   if (s > cap) s = cap;
   if (s < 1) s = 1;

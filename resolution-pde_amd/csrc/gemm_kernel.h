@@ -1,0 +1,329 @@
+// Strided batched fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   C[z][m,n] (+)= alpha * sum_k actA(A[z][m,k]) * actB(B[z][k,n])  (+ bias, * act'(aux))
+//
+// Every heavy operation of the hot path is expressed through this kernel:
+//   * the pointwise FeedForward / lifting / projection linears (forward NT,
+//     backward-data NN, weight-gradient TN with split-K over the grid points),
+//   * the truncated real DFTs (analysis [2K,n].X, synthesis [n,2K].A) for both
+//     channels-last (FFNO) and channels-first (FNO) tensors,
+//   * the per-mode complex channel mixing as real [rows,2C].[2C,2C] blocks.
+//
+// Design (MI355X_MICROARCH / cdna_hip_programming guides):
+//   * exact-fp32 MFMA 32x32x2: 64 cycles/SIMD per instruction, so LDS fragment
+//     traffic is far from the limit; the kernel is MFMA-issue bound when the
+//     reduction is long and HBM bound when it is short.
+//   * 256 threads = 4 waves arranged WM x WN, each wave TM x TN tiles of 32x32.
+//   * BK = 32 per stage, two LDS stages, register prefetch of the next stage's
+//     global loads (issue early / write late), one barrier per stage.
+//   * k order inside a stage is permuted (lane half h owns k = 16h .. 16h+15) so
+//     a k-major operand is read with ds_read_b128; row stride BK+4 dwords makes
+//     those reads bank-conflict free (36r mod 64 distinct multiples of 4).
+//   * operands may be k-major or "x-major" (the non-reduction index
+//     contiguous); both are loaded from HBM as coalesced 16-byte vectors along
+//     their contiguous index and stored to LDS in the same orientation.
+//   * activation (+ counter-hash dropout) is applied to ONE operand while it is
+//     staged (template PRO), so hidden activations are never written to HBM.
+//   * everything in the k-loop is resolved at compile time (VEC: 16-byte loads
+//     only; PRO: which operand is activated): the first version kept those as
+//     run-time branches and its loop body overflowed the instruction cache.
+//     Odd shapes / unaligned operands take the VEC=false instantiation.
+//   * with many M-tiles the N-tiles of one M-tile are dealt to one XCD (blocks b
+//     and b+8 share an L2) and reuse the A panel from that L2; with few tiles
+//     (batched / split-K launches) ids are dense so the batch index spreads
+//     the work over all 8 XCDs.
+#pragma once
+#include "rpde_internal.h"
+
+namespace rpde {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+struct GemmK {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  int zdiv, ztotal;
+  long sA1, sA2, sB1, sB2, sC1, sC2;
+  int ksplit, kchunk; long sCk;
+  float alpha; int accumulate;
+  const float* bias; int bias_mode;
+  int act_a, act_b, epi_dact, write_act;
+  const float* aux; long ldaux;
+  DropCfg drop; long drop_ld; int drop_where;
+  int mtiles, ntiles, swz;
+};
+
+template <int ROWS, bool KMAJOR, bool VEC, bool PRO>
+struct Tile {
+  static constexpr int NV = ROWS * BK / 4 / NTHREADS;          // float4 per thread
+  static constexpr int LDK = BK + 4;                           // k-major row stride
+  static constexpr int LDS_FLOATS = KMAJOR ? ROWS * LDK : BK * ROWS;
+  static_assert(NV >= 1, "tile too small for 256 threads");
+
+  __device__ __forceinline__ static void coords(int v, int& rr, int& kk) {
+    if (KMAJOR) { rr = v >> 3; kk = (v & 7) << 2; }
+    else { kk = v / (ROWS / 4); rr = (v % (ROWS / 4)) << 2; }
+  }
+
+  // HBM -> registers (zero fill outside [.., rmax) x [.., kend))
+  __device__ __forceinline__ static void load(float4 (&r)[NV], const float* __restrict__ base, long ld,
+                                              int r0, int rmax, int k0, int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int rr, kk;
+      coords(tid + i * NTHREADS, rr, kk);
+      const int gr = r0 + rr, gk = k0 + kk;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (VEC) {
+        // host guarantees: extent along the contiguous index is a multiple of 4 and 16-byte aligned
+        if (gr < rmax && gk < kend) {
+          const float* p = KMAJOR ? base + (long)gr * ld + gk : base + (long)gk * ld + gr;
+          val = *reinterpret_cast<const float4*>(p);
+        }
+      } else if (gr < rmax && gk < kend) {
+        if (KMAJOR) {
+          const float* p = base + (long)gr * ld + gk;
+          val.x = p[0];
+          if (gk + 1 < kend) val.y = p[1];
+          if (gk + 2 < kend) val.z = p[2];
+          if (gk + 3 < kend) val.w = p[3];
+        } else {
+          const float* p = base + (long)gk * ld + gr;
+          val.x = p[0];
+          if (gr + 1 < rmax) val.y = p[1];
+          if (gr + 2 < rmax) val.z = p[2];
+          if (gr + 3 < rmax) val.w = p[3];
+        }
+      }
+      r[i] = val;
+    }
+  }
+
+  // registers -> LDS, applying h = act(dropout(z)) when this operand is the activated one
+  __device__ __forceinline__ static void store(float* __restrict__ lds, const float4 (&r)[NV], int tid, int act,
+                                               bool use_drop, const DropCfg& drop, long drop_ld, int r0, int k0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int rr, kk;
+      coords(tid + i * NTHREADS, rr, kk);
+      float4 v = r[i];
+      if (PRO) {
+        if (use_drop) {
+          const long slow = KMAJOR ? (long)(r0 + rr) : (long)(k0 + kk);
+          const long fast = KMAJOR ? (long)(k0 + kk) : (long)(r0 + rr);
+          const uint64_t id = (uint64_t)(slow * drop_ld + fast);
+          float s[4];
+          if (VEC) {
+            drop_scale4(drop, id, s);            // id % 4 == 0: host checks drop_ld % 4 == 0
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] = drop_scale1(drop, id + j);
+          }
+          v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
+        }
+        if (act == RPDE_ACT_GELU) {
+          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+        } else if (act == RPDE_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      float* dst = KMAJOR ? (lds + rr * LDK + kk) : (lds + kk * ROWS + rr);
+      *reinterpret_cast<float4*>(dst) = v;
+    }
+  }
+
+  // fragment of 4 consecutive k-steps for MFMA lane (i = l31, half = lh), chunk q
+  __device__ __forceinline__ static void frag(const float* __restrict__ lds, int row, int lh, int q, float (&f)[4]) {
+    if (KMAJOR) {
+      const float4 t = *reinterpret_cast<const float4*>(lds + row * LDK + lh * (BK / 2) + q * 4);
+      f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = lds[(lh * (BK / 2) + q * 4 + j) * ROWS + row];
+    }
+  }
+};
+
+// PRO: 0 no staged activation, 1 on A, 2 on B
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PRO, bool VEC>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  using TA = Tile<BM, AK, VEC, PRO == 1>;
+  using TB = Tile<BN, BKM, VEC, PRO == 2>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (TA::LDS_FLOATS + TB::LDS_FLOATS)];
+  float* const As0 = smem;
+  float* const As1 = smem + TA::LDS_FLOATS;
+  float* const Bs0 = smem + 2 * TA::LDS_FLOATS;
+  float* const Bs1 = Bs0 + TB::LDS_FLOATS;
+
+  const int tid = threadIdx.x;
+  // ---- which tile, which batch entry, which K slice -------------------------
+  const int L = blockIdx.x;
+  int mt, nt;
+  if (g.swz) {
+    mt = (L / (8 * g.ntiles)) * 8 + (L & 7);
+    nt = (L >> 3) % g.ntiles;
+    if (mt >= g.mtiles) return;
+  } else {
+    mt = L / g.ntiles;
+    nt = L - mt * g.ntiles;
+  }
+  const int zz = blockIdx.z * gridDim.y + blockIdx.y;
+  if (zz >= g.ztotal) return;
+  const int z = zz / g.ksplit, ks = zz - z * g.ksplit;
+  const int z1 = z / g.zdiv, z2 = z - z1 * g.zdiv;
+  const float* __restrict__ A = g.A + z1 * g.sA1 + z2 * g.sA2;
+  const float* __restrict__ B = g.B + z1 * g.sB1 + z2 * g.sB2;
+  const long coff = z1 * g.sC1 + z2 * g.sC2 + (long)ks * g.sCk;
+  float* __restrict__ C = g.C + coff;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool drop_a = g.drop.on() && (g.drop_where & 1);
+  const bool drop_b = g.drop.on() && (g.drop_where & 2);
+  const bool drop_e = g.drop.on() && (g.drop_where & 4);
+  float4 ra[TA::NV], rb[TB::NV];
+  if (nkt > 0) {
+    TA::load(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
+    TB::load(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
+    TA::store(As0, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, kbeg);
+    TB::store(Bs0, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, kbeg);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float* as = (kt & 1) ? As1 : As0;
+    const float* bs = (kt & 1) ? Bs1 : Bs0;
+    const bool more = kt + 1 < nkt;
+    const int knext = kbeg + (kt + 1) * BK;
+    if (more) {  // issue the next stage's HBM loads before computing this one
+      TA::load(ra, A, g.lda, m0, g.M, knext, kend, tid);
+      TB::load(rb, B, g.ldb, n0, g.N, knext, kend, tid);
+    }
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) TA::frag(as, (wm * TM + i) * 32 + l31, lh, q, af[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) TB::frag(bs, (wn * TN + j) * 32 + l31, lh, q, bf[j]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      TA::store((kt & 1) ? As0 : As1, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);
+      TB::store((kt & 1) ? Bs0 : Bs1, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool plain = !g.epi_dact && !g.accumulate && !g.write_act;
+  const long ldc = g.ldc;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + l31;
+      if (n >= g.N) continue;
+      const float bn = g.bias_mode == 1 ? g.bias[n] : 0.f;
+      const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
+      float* __restrict__ cb = C + (long)mb * ldc + n;
+      if (plain) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = (r & 3) + 8 * (r >> 2);
+          if (mb + dm >= g.M) continue;
+          float v = fmaf(acc[i][j][r], g.alpha, bn);
+          if (g.bias_mode == 2) v += g.bias[mb + dm];
+          cb[dm * ldc] = v;
+        }
+      } else {
+        const float* __restrict__ ab = g.aux ? g.aux + coff + (long)mb * g.ldaux + n : nullptr;
+        const uint64_t idb = (uint64_t)((long)mb * g.drop_ld + n);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = (r & 3) + 8 * (r >> 2);
+          if (mb + dm >= g.M) continue;
+          float v = fmaf(acc[i][j][r], g.alpha, bn);
+          if (g.bias_mode == 2) v += g.bias[mb + dm];
+          if (g.epi_dact) {
+            float s = 1.f;
+            if (drop_e) s = drop_scale1(g.drop, idb + (uint64_t)(dm * g.drop_ld));
+            const float u = ab[dm * g.ldaux] * s;
+            v = v * dact_f(g.epi_dact, u) * s;
+          }
+          float* cp = cb + dm * ldc;
+          if (g.accumulate) v += *cp;
+          if (g.write_act) v = act_f(g.write_act, v);
+          *cp = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- host-side dispatch, instantiated once per operand layout (one translation
+// unit each, so the instantiations compile in parallel).  PM: bit p set <=> the
+// staged-activation variant PRO = p is built for this layout.
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PM, bool VEC>
+inline void launch_pro(const GemmK& g, int pro, dim3 grid, hipStream_t st) {
+  if (pro == 0) {
+    if constexpr ((PM & 1) != 0)
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 0, VEC>), grid, dim3(NTHREADS), 0, st, g);
+  } else if (pro == 1) {
+    if constexpr ((PM & 2) != 0)
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 1, VEC>), grid, dim3(NTHREADS), 0, st, g);
+  } else {
+    if constexpr ((PM & 4) != 0)
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 2, VEC>), grid, dim3(NTHREADS), 0, st, g);
+  }
+}
+
+template <bool AK, bool BKM, int PM>
+inline int launch_layout_impl(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st) {
+  if (!((PM >> pro) & 1)) {
+    set_error("gemm: staged activation on operand %d is not built for layout a_kmajor=%d b_kmajor=%d", pro, (int)AK, (int)BKM);
+    return RPDE_ERR_ARG;
+  }
+  if (!vec) launch_pro<2, 2, 1, 1, AK, BKM, PM, false>(g, pro, grid, st);            // 64 x 64, scalar loads
+  else if (bm == 128 && bn == 128) launch_pro<2, 2, 2, 2, AK, BKM, PM, true>(g, pro, grid, st);
+  else if (bm == 128 && bn == 64) launch_pro<4, 1, 1, 2, AK, BKM, PM, true>(g, pro, grid, st);
+  else if (bm == 64 && bn == 128) launch_pro<1, 4, 2, 1, AK, BKM, PM, true>(g, pro, grid, st);
+  else if (bm == 64 && bn == 64) launch_pro<2, 2, 1, 1, AK, BKM, PM, true>(g, pro, grid, st);
+  else if (bm == 128 && bn == 32) launch_pro<4, 1, 1, 1, AK, BKM, PM, true>(g, pro, grid, st);
+  else launch_pro<1, 4, 1, 1, AK, BKM, PM, true>(g, pro, grid, st);                   // 32 x 128
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+int launch_nt(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st);  // A k-major, B k-major
+int launch_nn(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st);  // A k-major, B x-major
+int launch_tn(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st);  // A x-major, B x-major
+int launch_tt(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st);  // A x-major, B k-major
+
+}  // namespace rpde

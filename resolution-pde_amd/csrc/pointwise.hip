@@ -10,19 +10,27 @@ namespace rpde {
 // ---------------------------------------------------------------------------
 // out[i] (+)= scale * sum_s slabs[s*stride + i]
 // ---------------------------------------------------------------------------
-__global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long n, int S, long stride,
-                               float scale, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// 64 consecutive outputs per block; the 4 waves split the slabs, LDS combines them
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long n,
+                                                      int S, long stride, float scale, int accumulate) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + tx;
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += slabs[(long)s * stride + i];
-  acc *= scale;
-  if (accumulate) acc += out[i];
-  out[i] = acc;
+  if (i < n)
+    for (int s = ty; s < S; s += 4) acc += slabs[(long)s * stride + i];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < n) {
+    acc = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    acc *= scale;
+    if (accumulate) acc += out[i];
+    out[i] = acc;
+  }
 }
 
 int reduce_slabs(const float* slabs, float* out, long n, int S, long stride, float scale, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, out, n, S, stride, scale, accumulate);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slabs, out, n, S, stride, scale, accumulate);
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;
 }

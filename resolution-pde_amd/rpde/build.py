@@ -70,7 +70,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if verbose:
                     print(f"[rpde.build] compiled {os.path.basename(s)}", flush=True)
     if jobs or force or not os.path.exists(LIB):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,--no-undefined", *objs, "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

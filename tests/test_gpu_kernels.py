@@ -128,7 +128,7 @@ def test_dropout_masks_agree_between_prologues_and_epilogue(gpu_device):
         return out.cpu()
 
     # A-operand prologue: identity act + dropout of ones, times I
-    m_a = run(A=ones.data_ptr(), lda=J, a_kmajor=1, B=eye_j.data_ptr(), ldb=J, b_kmajor=0, K=J, act_a=0, drop_where=1)
+    m_a = run(A=ones.data_ptr(), lda=J, a_kmajor=1, B=eye_j.data_ptr(), ldb=J, b_kmajor=1, K=J, act_a=0, drop_where=1)
     # B-operand prologue: I[P,P] times dropout(ones[P,J]) with points along the reduction
     m_b = run(A=eye_p.data_ptr(), lda=P, a_kmajor=1, B=ones.data_ptr(), ldb=J, b_kmajor=0, K=P, act_b=0, drop_where=2)
     # epilogue: acc = ones, aux large so gelu'(aux*s) is 1 where kept
