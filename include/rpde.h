@@ -86,6 +86,9 @@ typedef struct {
   float drop_p; uint64_t drop_seed; int64_t drop_ld;
   int write_act;           /* epilogue applies act (RPDE_ACT_*) to the stored value */
   int drop_where;
+  /* optional: per-M-tile column sums of the stored C, [ceil(M/128)][N] floats (bias gradients
+   * for free); needs M > 64, batch = ksplit = 1 and 16-byte aligned rows */
+  float* colsum;
 } rpde_gemm_desc;
 int rpde_gemm_f32(const rpde_gemm_desc* d, void* stream);
 

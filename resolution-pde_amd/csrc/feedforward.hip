@@ -67,8 +67,16 @@ static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* 
 }
 
 // gx[P,in] = gy[P,out] . W[out,in]   (optionally through act': * act'(drop(z)) * dropscale)
+static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline long colsum_tiles(long P) { return (P + 127) / 128; }
+// the backward-data GEMM can hand back per-tile column sums of gx (= the bias gradient of the layer below)
+static inline bool can_fuse_colsum(const float* gy, const float* w, const float* gx, const float* z, long P, int in_f,
+                                   int out_f) {
+  return P > 64 && in_f % 4 == 0 && out_f % 4 == 0 && al16p(gy) && al16p(w) && al16p(gx) && (!z || al16p(z));
+}
+
 static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f, int epi_dact,
-                             const float* z, float drop_p, uint64_t drop_seed, hipStream_t st) {
+                             const float* z, float drop_p, uint64_t drop_seed, float* colsum_slab, hipStream_t st) {
   rpde_gemm_desc d = gemm_desc();
   d.A = gy; d.a_kmajor = 1; d.lda = out_f;
   d.B = w; d.b_kmajor = 0; d.ldb = in_f;
@@ -76,6 +84,7 @@ static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P,
   d.M = (int)P; d.N = in_f; d.K = out_f;
   d.epi_dact = epi_dact; d.aux = z; d.ldaux = in_f;
   d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f; d.drop_where = 4;
+  d.colsum = colsum_slab;
   return launch_gemm(d, st);
 }
 
@@ -102,6 +111,8 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
   size_t small = colsum_ws_floats(P, hid);
   const size_t t = ff_tail_bwd_ws_floats(P, dim);
   if (t > small) small = t;
+  const size_t c = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
+  if (c > small) small = c;
   return 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small);
 }
 
@@ -141,27 +152,39 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   float* slabs = ar.take(slabs_n);
   size_t small_n = colsum_ws_floats(P, hid);
   if (ff_tail_bwd_ws_floats(P, p->dim) > small_n) small_n = ff_tail_bwd_ws_floats(P, p->dim);
+  if ((size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid > small_n) small_n = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
   float* small = ar.take(small_n);
   if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
 
-  // tail: d(out) -> dz_{L-1}, d(gamma), d(beta)
+  // tail: d(out) -> dz_{L-1}, d(gamma), d(beta) and, fused, the last layer's bias gradient
   float* dz = buf0;
   float* other = buf1;
+  int bias_done = 0;      // grad_biases[l] already produced by the kernel that produced dz_l
   RPDE_TRY(ff_tail_bwd(zs[L - 1], grad_out, dz, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
-                       make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, grad_gamma, grad_beta, small, st));
+                       make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, grad_gamma, grad_beta,
+                       grad_biases ? grad_biases[L - 1] : nullptr, &bias_done, small, st));
   for (int l = L - 1; l >= 0; --l) {
     const int in_f = ff_in(p, l), out_f = ff_out(p, l);
     const float* in = l == 0 ? x : zs[l - 1];
     const int act_in = l == 0 ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU;
     const float dp = l == 0 ? 0.f : p->dropout_p;
     const uint64_t sd = layer_seed(p->seed, l - 1);
-    RPDE_TRY(linear_wgrad_impl(in, dz, grad_weights ? grad_weights[l] : nullptr, grad_biases ? grad_biases[l] : nullptr, P,
-                               in_f, out_f, act_in, dp, sd, slabs, small, st));
+    float* gb = (grad_biases && !bias_done) ? grad_biases[l] : nullptr;
+    RPDE_TRY(linear_wgrad_impl(in, dz, grad_weights ? grad_weights[l] : nullptr, gb, P, in_f, out_f, act_in, dp, sd, slabs,
+                               small, st));
+    bias_done = 0;
     if (l > 0) {
-      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, RPDE_ACT_GELU, zs[l - 1], dp, sd, st));
+      const bool fuse = grad_biases && can_fuse_colsum(dz, p->weights[l], other, zs[l - 1], P, in_f, out_f);
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, RPDE_ACT_GELU, zs[l - 1], dp, sd,
+                                 fuse ? small : nullptr, st));
+      if (fuse) {
+        RPDE_TRY(reduce_slabs_2pass(small, grad_biases[l - 1], in_f, (int)colsum_tiles(P), in_f,
+                                    small + colsum_tiles(P) * in_f, st));
+        bias_done = 1;
+      }
       float* t = dz; dz = other; other = t;
     } else if (grad_x) {
-      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, 0, nullptr, 0.f, 0, st));
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, 0, nullptr, 0.f, 0, nullptr, st));
     }
   }
   return RPDE_OK;
@@ -186,7 +209,7 @@ int rpde_linear_bwd(const float* x, const float* w, const float* grad_out, float
   float* small = ar.take(colsum_ws_floats(P, out_f));
   if (!ar.ok()) { set_error("linear_bwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
   RPDE_TRY(linear_wgrad_impl(x, grad_out, grad_w, grad_b, P, in_f, out_f, RPDE_ACT_IDENTITY, 0.f, 0, slabs, small, st));
-  if (grad_x) RPDE_TRY(linear_dgrad_impl(grad_out, w, grad_x, P, in_f, out_f, 0, nullptr, 0.f, 0, st));
+  if (grad_x) RPDE_TRY(linear_dgrad_impl(grad_out, w, grad_x, P, in_f, out_f, 0, nullptr, 0.f, 0, nullptr, st));
   return RPDE_OK;
 }
 

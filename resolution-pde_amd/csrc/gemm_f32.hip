@@ -55,6 +55,14 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   const int gz = (int)((zt + gy - 1) / gy);
   dim3 grid(g.swz ? ((g.mtiles + 7) / 8) * 8 * g.ntiles : g.mtiles * g.ntiles, gy, gz);
 
+  // LDS-staged vector epilogue: C rows, aux rows, bias and the dropout ids must be 16-byte friendly
+  g.cvec = vec && al16(d.C) && (d.ldc % 4 == 0) && (d.sC1 % 4 == 0) && (d.sC2 % 4 == 0) && (d.sCk % 4 == 0) &&
+           (d.N % 4 == 0) && (!d.aux || (al16(d.aux) && d.ldaux % 4 == 0)) &&
+           (!(d.bias && d.bias_mode == 1) || al16(d.bias)) && (!(g.drop.on() && (d.drop_where & 4)) || d.drop_ld % 4 == 0);
+  g.colsum = d.colsum;
+  RPDE_CHECK_ARG(!d.colsum || (g.cvec && BMc == 128 && d.batch == 1 && d.ksplit == 1),
+                 "gemm: colsum needs the vector epilogue, M > 64 and a single un-split problem");
+
   if (ak && bk) return launch_nt(g, BMc, BNc, pro, vec, grid, st);
   if (ak && !bk) return launch_nn(g, BMc, BNc, pro, vec, grid, st);
   if (!ak && !bk) return launch_tn(g, BMc, BNc, pro, vec, grid, st);

@@ -55,6 +55,8 @@ struct GemmK {
   const float* aux; long ldaux;
   DropCfg drop; long drop_ld; int drop_where;
   int mtiles, ntiles, swz;
+  int cvec;          // C / aux / bias allow 16-byte row accesses: LDS-staged epilogue
+  float* colsum;     // optional [mtiles][N] per-M-tile column sums of the stored C
 };
 
 template <int ROWS, bool KMAJOR, bool VEC, bool PRO>
@@ -242,6 +244,74 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (VEC && g.cvec) {
+    // Stage the tile through LDS (the operand buffers are free after the loop's
+    // last barrier) so that HBM sees whole 16-byte vectors of contiguous rows:
+    // 4x fewer store / aux-load instructions, one dropout hash per 4 elements,
+    // and the per-tile column sums (bias gradients) come for free.
+    static_assert(BM * BN <= 2 * (TA::LDS_FLOATS + TB::LDS_FLOATS), "C tile must fit the operand staging buffers");
+    float* __restrict__ cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 32 + l31;
+        const int rb = (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * BN + col] = acc[i][j][r];
+      }
+    __syncthreads();
+    constexpr int VPR = BN / 4;                       // vectors per tile row
+    constexpr int NV4 = BM * BN / 4 / NTHREADS;       // vectors per thread
+    constexpr int RSTEP = NTHREADS / VPR;             // rows between a thread's vectors
+    const int c4 = (tid % VPR) * 4, row0 = tid / VPR;
+    const int gn = n0 + c4;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gn < g.N) {
+      float4 bn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.bias_mode == 1) bn4 = *reinterpret_cast<const float4*>(g.bias + gn);
+      const float* __restrict__ aux = g.aux ? g.aux + coff : nullptr;
+#pragma unroll 4
+      for (int it = 0; it < NV4; ++it) {
+        const int row = row0 + it * RSTEP;
+        const int gm = m0 + row;
+        if (gm >= g.M) break;
+        float4 v = *reinterpret_cast<const float4*>(cs + row * BN + c4);
+        v.x = fmaf(v.x, g.alpha, bn4.x); v.y = fmaf(v.y, g.alpha, bn4.y);
+        v.z = fmaf(v.z, g.alpha, bn4.z); v.w = fmaf(v.w, g.alpha, bn4.w);
+        if (g.bias_mode == 2) { const float bm = g.bias[gm]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+        if (g.epi_dact) {
+          float s[4] = {1.f, 1.f, 1.f, 1.f};
+          if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+          const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
+          v.x *= dact_f(g.epi_dact, a.x * s[0]) * s[0];
+          v.y *= dact_f(g.epi_dact, a.y * s[1]) * s[1];
+          v.z *= dact_f(g.epi_dact, a.z * s[2]) * s[2];
+          v.w *= dact_f(g.epi_dact, a.w * s[3]) * s[3];
+        }
+        float4* cp = reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn);
+        if (g.accumulate) { const float4 o = *cp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (g.write_act) {
+          v.x = act_f(g.write_act, v.x); v.y = act_f(g.write_act, v.y);
+          v.z = act_f(g.write_act, v.z); v.w = act_f(g.write_act, v.w);
+        }
+        *cp = v;
+        csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+      }
+    }
+    if (g.colsum) {      // uniform
+      __syncthreads();   // everyone is done reading cs
+      *reinterpret_cast<float4*>(cs + row0 * BN + c4) = csum;
+      __syncthreads();
+      if (tid < BN && n0 + tid < g.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < RSTEP; ++rr) t += cs[rr * BN + tid];
+        g.colsum[(long)mt * g.N + n0 + tid] = t;
+      }
+    }
+    return;
+  }
   const bool plain = !g.epi_dact && !g.accumulate && !g.write_act;
   const long ldc = g.ldc;
 #pragma unroll
@@ -253,35 +323,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
       const float bn = g.bias_mode == 1 ? g.bias[n] : 0.f;
       const int mb = m0 + (wm * TM + i) * 32 + 4 * lh;
       float* __restrict__ cb = C + (long)mb * ldc + n;
-      if (plain) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dm = (r & 3) + 8 * (r >> 2);
-          if (mb + dm >= g.M) continue;
-          float v = fmaf(acc[i][j][r], g.alpha, bn);
-          if (g.bias_mode == 2) v += g.bias[mb + dm];
-          cb[dm * ldc] = v;
-        }
-      } else {
-        const float* __restrict__ ab = g.aux ? g.aux + coff + (long)mb * g.ldaux + n : nullptr;
-        const uint64_t idb = (uint64_t)((long)mb * g.drop_ld + n);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dm = (r & 3) + 8 * (r >> 2);
-          if (mb + dm >= g.M) continue;
-          float v = fmaf(acc[i][j][r], g.alpha, bn);
-          if (g.bias_mode == 2) v += g.bias[mb + dm];
+      const float* __restrict__ ab = g.aux ? g.aux + coff + (long)mb * g.ldaux + n : nullptr;
+      const uint64_t idb = (uint64_t)((long)mb * g.drop_ld + n);
+#pragma unroll 4
+      for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2);
+        if (mb + dm >= g.M) continue;
+        float v = fmaf(acc[i][j][r], g.alpha, bn);
+        if (g.bias_mode == 2) v += g.bias[mb + dm];
+        if (!plain) {
           if (g.epi_dact) {
             float s = 1.f;
             if (drop_e) s = drop_scale1(g.drop, idb + (uint64_t)(dm * g.drop_ld));
             const float u = ab[dm * g.ldaux] * s;
             v = v * dact_f(g.epi_dact, u) * s;
           }
-          float* cp = cb + dm * ldc;
-          if (g.accumulate) v += *cp;
+          if (g.accumulate) v += cb[dm * ldc];
           if (g.write_act) v = act_f(g.write_act, v);
-          *cp = v;
         }
+        cb[dm * ldc] = v;
       }
     }
   }

@@ -5,6 +5,9 @@
 namespace rpde {
 
 int reduce_slabs(const float* slabs, float* out, long n, int S, long stride, float scale, int accumulate, hipStream_t st);
+constexpr int REDUCE_CHUNKS = 64;
+// tmp: REDUCE_CHUNKS * n floats of scratch
+int reduce_slabs_2pass(const float* slabs, float* out, long n, int S, long stride, float* tmp, hipStream_t st);
 
 size_t colsum_ws_floats(long P, int N);
 int colsum(const float* x, float* out, long P, int N, long ld, float* ws, int accumulate, hipStream_t st);
@@ -13,8 +16,8 @@ int ff_tail_fwd(const float* z, const float* res, float* out, long P, int C, int
                 const float* gamma, const float* beta, DropCfg drop, int post_act, hipStream_t st);
 size_t ff_tail_bwd_ws_floats(long P, int C);
 int ff_tail_bwd(const float* z, const float* g, float* dz, long P, int C, int layer_norm, float eps, const float* gamma,
-                const float* beta, DropCfg drop, int post_act, float* grad_gamma, float* grad_beta, float* ws,
-                hipStream_t st);
+                const float* beta, DropCfg drop, int post_act, float* grad_gamma, float* grad_beta, float* grad_bias,
+                int* bias_done, float* ws, hipStream_t st);
 
 int pack_mix_weights(const float* w, float* blk, int Ci, int Co, int K, int keff, hipStream_t st);
 int unpack_mix_grad(const float* slabs, float* gw, int Ci, int Co, int K, int keff, int S, long sstride, hipStream_t st);

@@ -35,6 +35,30 @@ int reduce_slabs(const float* slabs, float* out, long n, int S, long stride, flo
   return RPDE_OK;
 }
 
+// many slabs, few outputs (per-tile column sums): first fold S slabs into REDUCE_CHUNKS
+// partial rows (tmp [REDUCE_CHUNKS][n]) with one block per (64 outputs, chunk), then fold those
+__global__ __launch_bounds__(256) void k_reduce_slabs_chunk(const float* __restrict__ slabs, float* __restrict__ tmp, long n,
+                                                            int S, long stride, int per_chunk) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + tx;
+  const int s0 = blockIdx.y * per_chunk, s1 = min(S, s0 + per_chunk);
+  float acc = 0.f;
+  if (i < n)
+    for (int s = s0 + ty; s < s1; s += 4) acc += slabs[(long)s * stride + i];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < n) tmp[(long)blockIdx.y * n + i] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+int reduce_slabs_2pass(const float* slabs, float* out, long n, int S, long stride, float* tmp, hipStream_t st) {
+  if (S <= 4 * REDUCE_CHUNKS) return reduce_slabs(slabs, out, n, S, stride, 1.f, 0, st);
+  const int per = (S + REDUCE_CHUNKS - 1) / REDUCE_CHUNKS;
+  hipLaunchKernelGGL(k_reduce_slabs_chunk, dim3((unsigned)((n + 63) / 64), REDUCE_CHUNKS), dim3(256), 0, st, slabs, tmp, n, S, stride, per);
+  RPDE_LAUNCH_CHECK();
+  return reduce_slabs(tmp, out, n, REDUCE_CHUNKS, n, 1.f, 0, st);
+}
+
 // ---------------------------------------------------------------------------
 // column sums of x [P, N] (row stride ld): slab[block][n] partials
 // ---------------------------------------------------------------------------
@@ -283,17 +307,117 @@ __global__ __launch_bounds__(256) void k_ff_tail_bwd(const float* __restrict__ z
   }
 }
 
+// vector form: a row of C = 4G floats is owned by G lanes (float4 each); every
+// thread keeps the same 4 columns for all its rows, so d(gamma), d(beta) and the
+// bias gradient sum(dz) accumulate in registers and meet once in LDS.
+// slab[block][3][C] = (sum dy*xhat, sum dy, sum dz)
+template <int G>
+__global__ __launch_bounds__(256) void k_ff_tail_bwd_vec(const float* __restrict__ z, const float* __restrict__ g,
+                                                         float* __restrict__ dz, float* __restrict__ slab, long P,
+                                                         int layer_norm, float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, DropCfg drop, int post_act) {
+  constexpr int C = 4 * G;
+  constexpr int RPB = 256 / G;
+  __shared__ float red[3][RPB][C];
+  const int lir = threadIdx.x % G, rib = threadIdx.x / G;
+  float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (layer_norm) {
+    gm = *reinterpret_cast<const float4*>(gamma + lir * 4);
+    bt = *reinterpret_cast<const float4*>(beta + lir * 4);
+  }
+  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, ds[4] = {0.f, 0.f, 0.f, 0.f};
+  const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+  for (long row = (long)blockIdx.x * RPB + rib; row < P; row += (long)gridDim.x * RPB) {
+    const long off = row * C + lir * 4;
+    const float4 z4 = *reinterpret_cast<const float4*>(z + off);
+    const float4 g4 = *reinterpret_cast<const float4*>(g + off);
+    float s[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop.on()) drop_scale4(drop, (uint64_t)off, s);
+    const float t[4] = {z4.x * s[0], z4.y * s[1], z4.z * s[2], z4.w * s[3]};
+    const float gy[4] = {g4.x, g4.y, g4.z, g4.w};
+    float o[4];
+    if (layer_norm) {
+      const float mean = group_sum<G>(t[0] + t[1] + t[2] + t[3]) * (1.f / C);
+      float d[4], sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { d[k] = t[k] - mean; sq += d[k] * d[k]; }
+      const float rstd = rsqrtf(group_sum<G>(sq) * (1.f / C) + eps);
+      float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xh[k] = d[k] * rstd;
+        float dy = gy[k];
+        if (post_act) dy *= dact_f(post_act, xh[k] * gmv[k] + btv[k]);
+        dg[k] += dy * xh[k];
+        db[k] += dy;
+        dxh[k] = dy * gmv[k];
+        s1 += dxh[k];
+        s2 += dxh[k] * xh[k];
+      }
+      s1 = group_sum<G>(s1) * (1.f / C);
+      s2 = group_sum<G>(s2) * (1.f / C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = rstd * (dxh[k] - s1 - xh[k] * s2) * s[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = gy[k] * dact_f(post_act, t[k]) * s[k];
+    }
+    *reinterpret_cast<float4*>(dz + off) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ds[k] += o[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[0][rib][lir * 4 + k] = dg[k];
+    red[1][rib][lir * 4 + k] = db[k];
+    red[2][rib][lir * 4 + k] = ds[k];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 3 * C; idx += 256) {
+    const int w = idx / C, c = idx % C;
+    float a = 0.f;
+#pragma unroll 4
+    for (int r = 0; r < RPB; ++r) a += red[w][r][c];
+    slab[(long)blockIdx.x * 3 * C + idx] = a;
+  }
+}
+
 static long tail_bwd_blocks(long P) {
   long nb = (P + 3) / 4;
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return nb;
 }
-size_t ff_tail_bwd_ws_floats(long P, int C) { return (size_t)tail_bwd_blocks(P) * 2 * C; }
+static bool tail_vec_ok(int C) {
+  const int G = C / 4;
+  return (C % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64);
+}
+size_t ff_tail_bwd_ws_floats(long P, int C) { return (size_t)tail_bwd_blocks(P) * 3 * C; }
 
+// grad_bias (optional) receives colsum(dz) when the vector kernel runs; returns whether it did
 int ff_tail_bwd(const float* z, const float* g, float* dz, long P, int C, int layer_norm, float eps, const float* gamma,
-                const float* beta, DropCfg drop, int post_act, float* grad_gamma, float* grad_beta, float* ws,
-                hipStream_t st) {
+                const float* beta, DropCfg drop, int post_act, float* grad_gamma, float* grad_beta, float* grad_bias,
+                int* bias_done, float* ws, hipStream_t st) {
+  *bias_done = 0;
+  if (tail_vec_ok(C)) {
+    const int G = C / 4;
+    const long rpb = 256 / G;
+    long nb = (P + rpb - 1) / rpb; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+#define LAUNCH_G(GG) hipLaunchKernelGGL((k_ff_tail_bwd_vec<GG>), dim3((unsigned)nb), dim3(256), 0, st, z, g, dz, ws, P, layer_norm, eps, gamma, beta, drop, post_act)
+    switch (G) {
+      case 1: LAUNCH_G(1); break; case 2: LAUNCH_G(2); break; case 4: LAUNCH_G(4); break;
+      case 8: LAUNCH_G(8); break; case 16: LAUNCH_G(16); break; case 32: LAUNCH_G(32); break;
+      default: LAUNCH_G(64); break;
+    }
+#undef LAUNCH_G
+    RPDE_LAUNCH_CHECK();
+    if (layer_norm) {
+      if (grad_gamma) RPDE_TRY(reduce_slabs(ws, grad_gamma, C, (int)nb, 3L * C, 1.f, 0, st));
+      if (grad_beta) RPDE_TRY(reduce_slabs(ws + C, grad_beta, C, (int)nb, 3L * C, 1.f, 0, st));
+    }
+    if (grad_bias) { RPDE_TRY(reduce_slabs(ws + 2 * C, grad_bias, C, (int)nb, 3L * C, 1.f, 0, st)); *bias_done = 1; }
+    return RPDE_OK;
+  }
   RPDE_CHECK_ARG(C <= 512, "ff_tail_bwd: width %d > 512 unsupported", C);
   const long nb = tail_bwd_blocks(P);
   hipLaunchKernelGGL(k_ff_tail_bwd, dim3((unsigned)nb), dim3(256), 0, st, z, g, dz, ws, P, C, layer_norm, eps, gamma, beta, drop, post_act);
