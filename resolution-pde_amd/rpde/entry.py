@@ -1,0 +1,90 @@
+"""Shared body of main_1d.py / main_2d.py: compose config, build data, model,
+optimiser and scheduler, train, test, checkpoint -- the sequence of the
+reference's entry points (main_1d.py:34-309, main_2d.py:38-324) minus wandb,
+plotting and the HDF5 loaders (out of scope / row f4)."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.optim as optim
+
+from rpde.config import compose, instantiate
+
+
+def _init_distributed():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    return world, rank, local
+
+
+def run(dims: int, argv=None):
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = compose(os.path.join(here, "conf"), "config", list(sys.argv[1:] if argv is None else argv))
+    if int(args.dataset.dims) != dims:
+        raise SystemExit(f"main_{dims}d.py needs a {dims}-D dataset config, got dims={args.dataset.dims}")
+    world, rank, local = _init_distributed()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from train.mres_training import ResolutionGroupedDataLoader
+    from train.training import evaluate, train
+    from utils.synthetic import markov_pairs
+
+    seed = int(args.training.get("seed", 0))
+    bs = int(args.training.batch_size)
+    train_set = markov_pairs(args.dataset.resolutions, dims, seed)
+    top = max(int(r) for r in dict(args.dataset.resolutions))
+    val_set = markov_pairs({top: int(args.dataset.n_val)}, dims, seed + 50000)
+    test_set = markov_pairs({top: int(args.dataset.n_test)}, dims, seed + 60000)
+    mk = lambda ds, shuffle: ResolutionGroupedDataLoader(ds, bs, shuffle=shuffle, seed=seed, rank=rank,  # noqa: E731
+                                                         world_size=world, verbose=rank == 0)
+    train_loader, val_loader, test_loader = mk(train_set, True), mk(val_set, False), mk(test_set, False)
+
+    torch.manual_seed(seed)                                   # same initial weights on every rank
+    model = instantiate(args.model).to(device)
+    ckpt = args.dataset.get("saved_checkpoint_path")
+    if ckpt:
+        state = torch.load(ckpt, map_location=device, weights_only=True)
+        model.load_state_dict(state["model_state_dict"])
+
+    lr = float(args.training.learning_rate)
+    if dims == 2:     # reference main_2d.py:173-174
+        optimizer = optim.AdamW(model.parameters(), lr=lr)
+        scheduler = optim.lr_scheduler.StepLR(optimizer, step_size=30, gamma=0.5)
+    else:             # reference main_1d.py:144-145
+        optimizer = optim.AdamW(model.parameters(), lr=lr, weight_decay=1e-4)
+        scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=100, eta_min=1e-5)
+
+    n_params = sum(p.numel() for p in model.parameters())
+    if rank == 0:
+        print(json.dumps({"model": args.model["_target_"], "params": n_params, "world": world,
+                          "train_batches": len(train_loader), "choices": args["_choices_"]}), flush=True)
+    t0 = time.time()
+    loss_hist, val_hist = train(model, train_loader, val_loader, optimizer, scheduler,
+                                use_normalizer=bool(args.training.use_normalizer), epochs=int(args.training.epochs),
+                                device=device)
+    torch.cuda.synchronize()
+    test_l2 = evaluate(model, test_loader, device=device)
+    if rank == 0:
+        print(json.dumps({"train_seconds": round(time.time() - t0, 3), "final_train_loss": loss_hist[-1],
+                          "final_val_loss": val_hist[-1], "test_rel_l2": test_l2}), flush=True)
+        os.makedirs(args.checkpoint_dir, exist_ok=True)
+        path = os.path.join(args.checkpoint_dir, f"{args.project_name}_{dims}d.pt")
+        torch.save({"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                    "loss_history": loss_hist, "val_loss_history": val_hist, "l2_loss": test_l2}, path)
+        print(json.dumps({"checkpoint": path}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return test_l2

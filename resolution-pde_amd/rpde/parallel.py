@@ -26,9 +26,10 @@ class FlatGradBucket:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         sizes = [p.numel() * (2 if p.is_complex() else 1) for p in self.params]
-        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        padded = [(n + 3) // 4 * 4 for n in sizes]          # 16-byte aligned chunks (complex views need even offsets)
+        self.flat = torch.zeros(sum(padded), dtype=torch.float32, device=dev)
         off = 0
-        for p, n in zip(self.params, sizes):
+        for p, n, step in zip(self.params, sizes, padded):
             chunk = self.flat[off:off + n]
             if p.is_complex():
                 p.grad = torch.view_as_complex(chunk.view(*p.shape, 2))
@@ -36,7 +37,7 @@ class FlatGradBucket:
                 if p.dtype != torch.float32:
                     raise TypeError(f"expected fp32 / complex64 parameters, got {p.dtype}")
                 p.grad = chunk.view(p.shape)
-            off += n
+            off += step
 
     @property
     def nbytes(self) -> int:

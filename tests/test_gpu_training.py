@@ -1,0 +1,110 @@
+"""GPU: the training-side behaviour that golden vectors cannot pin -- dropout
+(statistical parity only, SURVEY hard part 3), mixed-resolution batches, and
+the Hydra-shaped entry points end to end."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dropout_statistics_and_eval_mode(gpu_device):
+    from models.custom_layer import FeedForward
+    torch.manual_seed(0)
+    ff = FeedForward(64, 4, n_layers=3, layer_norm=False, dropout=0.25).to(gpu_device)
+    x = torch.randn(4096, 64, device=gpu_device)
+    ff.eval()
+    e1, e2 = ff(x), ff(x)
+    assert torch.equal(e1, e2)
+    ff.train()
+    t1, t2 = ff(x), ff(x)
+    assert not torch.equal(t1, t2)                       # fresh mask per call
+    # last layer: out = dropout(z3) -> a fraction p of the outputs is exactly zero
+    frac = (t1 == 0).float().mean().item()
+    assert abs(frac - 0.25) < 0.01, frac
+    # inverted dropout keeps the expectation: the mean over many masks approaches eval output
+    acc = torch.zeros_like(e1)
+    n = 64
+    for _ in range(n):
+        acc += ff(x)
+    rel = float((acc / n - e1).norm() / e1.norm())
+    assert rel < 0.35, rel                               # E[gelu(drop z)] != gelu(z) exactly; loose statistical bound
+
+
+def test_dropout_backward_regenerates_the_forward_mask(gpu_device):
+    """directional finite difference of the *stochastic* layer with a pinned seed"""
+    from models.custom_layer import FeedForward
+    torch.manual_seed(1)
+    ff = FeedForward(32, 2, n_layers=3, layer_norm=True, dropout=0.3).to(gpu_device).train()
+    x = torch.randn(512, 32, device=gpu_device, dtype=torch.float32)
+    cot = torch.randn(512, 32, device=gpu_device)
+    v = torch.randn_like(x)
+    v /= v.norm()
+
+    def loss_at(xx):
+        torch.manual_seed(1234)                          # the layer draws its mask seed from the CPU generator
+        return (ff(xx) * cot).sum()
+
+    xr = x.clone().requires_grad_(True)
+    loss_at(xr).backward()
+    analytic = float((xr.grad * v).sum())
+    eps = 2e-2
+    numeric = float((loss_at(x + eps * v).double() - loss_at(x - eps * v).double()) / (2 * eps))
+    assert abs(analytic - numeric) <= 3e-2 * max(1.0, abs(numeric)), (analytic, numeric)
+    # parameter gradients too: perturb the first weight along a random direction
+    w = ff.layers[0][0].weight
+    dw = torch.randn_like(w)
+    dw /= dw.norm()
+    ff.zero_grad()
+    loss_at(x).backward()
+    analytic_w = float((w.grad * dw).sum())
+    with torch.no_grad():
+        w.add_(eps * dw)
+        lp = loss_at(x).double()
+        w.sub_(2 * eps * dw)
+        lm = loss_at(x).double()
+        w.add_(eps * dw)
+    numeric_w = float((lp - lm) / (2 * eps))
+    assert abs(analytic_w - numeric_w) <= 3e-2 * max(1.0, abs(numeric_w)), (analytic_w, numeric_w)
+
+
+def test_mixed_resolution_batches_share_weights(gpu_device):
+    """the same FFNO2D weights run 32^2 (clamped modes), 48x64 and 64^2 batches back to back"""
+    from models.ffno import FFNO2D
+    from utils.loss import RelativeL2Loss
+    torch.manual_seed(0)
+    m = FFNO2D(1, 1, width=16, n_layers=2, n_modes=20, factor=2, ff_weight_norm=True, n_ff_layers=2,
+               layer_norm=True, dropout=0.1).to(gpu_device).train()
+    loss_fn = RelativeL2Loss()
+    for shape in [(2, 1, 32, 32), (3, 1, 48, 64), (1, 1, 64, 64), (2, 1, 32, 32)]:
+        x = torch.randn(*shape, device=gpu_device)
+        loss = loss_fn(m(x), torch.randn(*shape, device=gpu_device))
+        loss.backward()
+        assert torch.isfinite(loss)
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_main_2d_trains_and_checkpoints(gpu_device, tmp_path, capsys):
+    from rpde.entry import run
+    l2 = run(2, ["model=ffno_2d/ffno_2d", "dataset=synthetic/ns_mres", "dataset.resolutions={32: 24, 48: 24}",
+                 "dataset.n_val=8", "dataset.n_test=8", "model.width=16", "model.n_layers=2", "model.n_modes=8",
+                 "model.factor=2", "training.epochs=6", "training.batch_size=8", "training.learning_rate=0.003",
+                 f"checkpoint_dir={tmp_path}"])
+    out = capsys.readouterr().out
+    first = [ln for ln in out.splitlines() if '"epoch": 0' in ln]
+    assert first and l2 < 1.0
+    import json
+    e0 = json.loads(first[0])
+    assert l2 < e0["val_loss"], (l2, e0)                 # learning happened
+    ck = torch.load(tmp_path / "rpde_mi355x_2d.pt", weights_only=True)
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "loss_history", "val_loss_history", "l2_loss"}
+
+
+def test_main_1d_fno_and_ffno(gpu_device, tmp_path):
+    from rpde.entry import run
+    for model in ("ffno_1d/ffno_1d", "fno_1d/fno_1d"):
+        extra = ["model.width=16", "model.n_layers=2", "model.n_modes=8", "model.factor=2"] if "ffno" in model else \
+                ["model.width=16", "model.modes=8"]
+        l2 = run(1, [f"model={model}", "dataset=synthetic/ks_512", "dataset.resolutions={64: 32}", "dataset.n_val=8",
+                     "dataset.n_test=8", "training.epochs=3", "training.batch_size=8", f"checkpoint_dir={tmp_path}"]
+                 + extra)
+        assert l2 == l2 and l2 < 2.0
