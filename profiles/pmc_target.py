@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Runs only the dominant kernel (FeedForward 256->256 GEMM with staged GELU+dropout, B*65536 points)
+and the spectral forward a few times: the target of the separate rocprofv3 --pmc passes
+(FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950, MI355X_MICROARCH.md 'PMC slots')."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "resolution-pde_amd"))
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+print("ff gemm", bench.time_ff_gemm(B, dev, iters=3))
+print("spectral", bench.time_spectral(B, dev, iters=2))
