@@ -167,18 +167,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="samples per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal aid: RPDE_DIST_BACKEND=gloo RPDE_SHARE_GPU=1 runs all ranks on cuda:0 (1-GPU box)
+    backend = os.environ.get("RPDE_DIST_BACKEND", "nccl")
+    if os.environ.get("RPDE_SHARE_GPU") == "1":
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 

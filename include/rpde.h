@@ -40,6 +40,7 @@ enum { RPDE_NORM_BACKWARD = 0, RPDE_NORM_ORTHO = 1, RPDE_NORM_FORWARD = 2 };
 enum { RPDE_MODE_FULL = 0, RPDE_MODE_LOWPASS = 1 };
 /* activations (models/spectral_convolution.py:104-106, fno_blocks.py:33,71) */
 enum { RPDE_ACT_IDENTITY = 0, RPDE_ACT_GELU = 1, RPDE_ACT_RELU = 2 };
+enum { RPDE_EPI_MULAUX = 100 };
 
 const char* rpde_last_error(void);
 int rpde_version(void);
@@ -78,8 +79,9 @@ typedef struct {
   const float* bias; int bias_mode;   /* 0 none, 1 bias[n], 2 bias[m]                */
   /* activation applied to an operand while it is staged (h = act(drop(z))) */
   int act_a, act_b;        /* RPDE_ACT_*                                            */
-  /* epilogue: C = acc * act'(drop(aux)) * dropscale   (backward through act)      */
-  int epi_dact;            /* RPDE_ACT_* or 0                                       */
+  /* epilogue: C = acc * act'(drop(aux)) * dropscale   (backward through act), or with
+   * RPDE_EPI_MULAUX: C = acc * aux (aux holds a stored derivative)                */
+  int epi_dact;            /* RPDE_ACT_*, RPDE_EPI_MULAUX or 0                      */
   const float* aux; int64_t ldaux;
   /* dropout shared by prologue / epilogue: element id = point*drop_ld + feature;
    * drop_where: bit 0 mask the A operand, bit 1 the B operand, bit 2 the epilogue's aux */
@@ -89,6 +91,10 @@ typedef struct {
   /* optional: per-M-tile column sums of the stored C, [ceil(M/128)][N] floats (bias gradients
    * for free); needs M > 64, batch = ksplit = 1 and 16-byte aligned rows */
   float* colsum;
+  /* with write_act and a non-null aux_out (same layout as C): the epilogue evaluates the activation
+   * once per element, u = dropout(acc+bias): C = act(u), aux_out = act'(u) * dropscale -- so every
+   * consumer of the hidden activation and of its derivative is a plain GEMM (drop_where bit 2) */
+  float* aux_out;
 } rpde_gemm_desc;
 int rpde_gemm_f32(const rpde_gemm_desc* d, void* stream);
 
@@ -151,12 +157,14 @@ int rpde_spectral2d_bwd(const float* grad_out, const float* spec_in, const float
 
 /* ---- FeedForward  (models/custom_layer.py:49-68) + the residual glue of
  * FFNO*.forward (models/ffno.py:118,230) and FSpectralConv1d's act (:154).
- * x [P,dim] channels-last points.  Per layer l: z_l = in_l @ W_l^T + b_l is
- * stored in zs[l] ([P,out_l]); in_{l+1} = gelu(dropout(z_l)) is applied while
- * z_l is staged for the next GEMM, never materialised.  The last layer:
- * out = residual + post_act( LayerNorm( dropout(z_last) ) )   (LN optional,
- * residual may be NULL).  Dropout masks come from a counter hash of
- * (seed, layer, element) and are regenerated in backward. */
+ * x [P,dim] channels-last points.  Hidden layer l < L-1: z_l = in_l @ W_l^T + b_l
+ * never reaches HBM; the GEMM epilogue evaluates the activation once per element,
+ * u = dropout(z_l): hs[l] = gelu(u) ([P,out_l], input of the next GEMM and of the
+ * weight-gradient GEMM) and ds[l] = gelu'(u) * dropscale (what backward multiplies
+ * by; pass ds = NULL or ds[l] = NULL when no gradient is needed).  The last layer
+ * stores z_last ([P,dim]) and out = residual + post_act( LayerNorm( dropout(z_last) ) )
+ * (LN optional, residual may be NULL).  Dropout masks come from a counter hash of
+ * (seed, layer, element). */
 typedef struct {
   int n_layers; int dim; int factor;
   int layer_norm; float ln_eps;
@@ -168,9 +176,10 @@ typedef struct {
 } rpde_ff_params;
 size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers);
 int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual,
-                         float* const* zs, float* out, int64_t P,
+                         float* const* hs, float* const* ds, float* z_last, float* out, int64_t P,
                          void* ws, size_t ws_bytes, void* stream);
-int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* const* zs,
+int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* const* hs,
+                         const float* const* ds, const float* z_last,
                          const float* grad_out, float* grad_x,
                          float* const* grad_weights, float* const* grad_biases,
                          float* grad_gamma, float* grad_beta, int64_t P,

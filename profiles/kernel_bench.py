@@ -56,13 +56,25 @@ def main():
     run("fwd NT 256->256 gelu(A)", P, 256, 256, 1, 1, bias=bias, bias_mode=1, act_a=1)
     run("fwd NT 256->256 gelu+drop(A)", P, 256, 256, 1, 1, bias=bias, bias_mode=1, act_a=1, drop_p=0.1, drop_seed=7,
         drop_ld=256, drop_where=1)
+    hout = torch.empty(P * 256, device=dev)
+    run("fwd NT 256->256 -> h=gelu(drop z), d=gelu'", P, 256, 256, 1, 1, bias=bias, bias_mode=1, write_act=1, aux_out=hout,
+        drop_p=0.1, drop_seed=7, drop_ld=256, drop_where=4)
+    run("fwd NT 64->256 -> h, d", P, 256, 64, 1, 1, bias=bias, bias_mode=1, write_act=1, aux_out=hout, drop_p=0.1,
+        drop_seed=7, drop_ld=256, drop_where=4)
+    run("fwd NT 64->256 -> h only (eval)", P, 256, 64, 1, 1, bias=bias, bias_mode=1, write_act=1)
+    del hout
     run("fwd NT 64->256 plain", P, 256, 64, 1, 1, bias=bias, bias_mode=1)
+    run("fwd NT 256->64 plain", P, 64, 256, 1, 1)
     run("fwd NT 256->64 gelu+drop(A)", P, 64, 256, 1, 1, act_a=1, drop_p=0.1, drop_seed=7, drop_ld=256, drop_where=1)
     aux = torch.randn(P * 256, device=dev)
     run("dgrad NN 256->256 plain", P, 256, 256, 1, 0)
     run("dgrad NN 256->256 gelu'(aux)", P, 256, 256, 1, 0, epi_dact=1, aux=aux, ldaux=256)
     run("dgrad NN 256->256 gelu'+drop+colsum", P, 256, 256, 1, 0, epi_dact=1, aux=aux, ldaux=256, drop_p=0.1, drop_seed=7,
         drop_ld=256, drop_where=4, colsum=torch.empty((P // 128) * 256, device=dev))
+    run("dgrad NN 256->256 * stored d + colsum", P, 256, 256, 1, 0, epi_dact=100, aux=aux, ldaux=256,
+        colsum=torch.empty((P // 128) * 256, device=dev))
+    run("dgrad NN 64->256 * stored d + colsum", P, 256, 64, 1, 0, epi_dact=100, aux=aux, ldaux=256,
+        colsum=torch.empty((P // 128) * 256, device=dev))
     run("dgrad NN 64->256 gelu'+drop", P, 256, 64, 1, 0, epi_dact=1, aux=aux, ldaux=256, drop_p=0.1, drop_seed=7,
         drop_ld=256, drop_where=4)
     del aux

@@ -1,10 +1,12 @@
 // FeedForward (models/custom_layer.py:49-68) and the pointwise linears /
 // 1x1 convolutions around the spectral layers, as fp32-MFMA GEMMs.
 //
-// Forward keeps only the pre-activations z_l in HBM.  h_l = gelu(dropout(z_l))
-// is recomputed while z_l is staged into LDS for the next GEMM (forward), for
-// the weight-gradient GEMM (backward) and inside the backward-data epilogue, so
-// the 4x wider hidden activations are written once and never re-materialised.
+// Each hidden pre-activation z_l stays on chip: the producing GEMM's epilogue evaluates the
+// activation ONCE per element, u = dropout(z_l), and stores h_l = gelu(u) (input of the next GEMM
+// and of the weight-gradient GEMM) and, when training, d_l = gelu'(u) * dropscale (what the
+// backward-data GEMM multiplies by).  Every consumer is then a plain GEMM.  (Round-1 history: the
+// first design re-evaluated gelu while staging z_l into LDS -- 5 evaluations per element over a
+// training step, costing 25-30 % of each fused GEMM; see profiles/r01_b_kernel_bench.txt.)
 #include "rpde_internal.h"
 #include "pointwise.h"
 
@@ -31,28 +33,29 @@ static inline int wgrad_split(long P, int out_f, int in_f) {
 }
 
 // y[P,out] = act_in(x)[P,in] . W[out,in]^T + b
-static int linear_fwd_impl(const float* x, const float* w, const float* b, float* y, long P, int in_f, int out_f, int act_in,
-                           float drop_p, uint64_t drop_seed, hipStream_t st) {
+// act_out != 0: y = act(dropout(z)) and, if dy, dy = act'(dropout(z)) * dropscale (mask of THIS layer's output)
+static int linear_fwd_impl(const float* x, const float* w, const float* b, float* y, long P, int in_f, int out_f,
+                           int act_out, float* dy, float drop_p, uint64_t drop_seed, hipStream_t st) {
   rpde_gemm_desc d = gemm_desc();
   d.A = x; d.a_kmajor = 1; d.lda = in_f;
   d.B = w; d.b_kmajor = 1; d.ldb = in_f;
   d.C = y; d.ldc = out_f;
   d.M = (int)P; d.N = out_f; d.K = in_f;
   d.bias = b; d.bias_mode = b ? 1 : 0;
-  d.act_a = act_in; d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f; d.drop_where = 1;
+  d.write_act = act_out; d.aux_out = act_out ? dy : nullptr;
+  if (act_out) { d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = out_f; d.drop_where = 4; }
   return launch_gemm(d, st);
 }
 
 // gw[out,in] = gy[P,out]^T . act_in(x)[P,in]   (split over P, slabs reduced here);  gb = colsum(gy)
-static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, long P, int in_f, int out_f, int act_in,
-                             float drop_p, uint64_t drop_seed, float* ws_slabs, float* ws_colsum, hipStream_t st) {
+static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, long P, int in_f, int out_f,
+                             float* ws_slabs, float* ws_colsum, hipStream_t st) {
   if (gw) {
     const int S = wgrad_split(P, out_f, in_f);
     rpde_gemm_desc d = gemm_desc();
     d.A = gy; d.a_kmajor = 0; d.lda = out_f;
     d.B = x; d.b_kmajor = 0; d.ldb = in_f;
     d.M = out_f; d.N = in_f; d.K = (int)P;
-    d.act_b = act_in; d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f; d.drop_where = 2;
     if (S > 1) {
       d.C = ws_slabs; d.ldc = in_f; d.ksplit = S; d.sCk = (long)out_f * in_f;
       RPDE_TRY(launch_gemm(d, st));
@@ -75,15 +78,15 @@ static inline bool can_fuse_colsum(const float* gy, const float* w, const float*
   return P > 64 && in_f % 4 == 0 && out_f % 4 == 0 && al16p(gy) && al16p(w) && al16p(gx) && (!z || al16p(z));
 }
 
-static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f, int epi_dact,
-                             const float* z, float drop_p, uint64_t drop_seed, float* colsum_slab, hipStream_t st) {
+// gx[P,in] = (gy[P,out] . W[out,in]) (* dstored[P,in] when given: the derivative saved by the forward epilogue)
+static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f,
+                             const float* dstored, float* colsum_slab, hipStream_t st) {
   rpde_gemm_desc d = gemm_desc();
   d.A = gy; d.a_kmajor = 1; d.lda = out_f;
   d.B = w; d.b_kmajor = 0; d.ldb = in_f;
   d.C = gx; d.ldc = in_f;
   d.M = (int)P; d.N = in_f; d.K = out_f;
-  d.epi_dact = epi_dact; d.aux = z; d.ldaux = in_f;
-  d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = in_f; d.drop_where = 4;
+  if (dstored) { d.epi_dact = RPDE_EPI_MULAUX; d.aux = dstored; d.ldaux = in_f; }
   d.colsum = colsum_slab;
   return launch_gemm(d, st);
 }
@@ -116,30 +119,34 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
   return 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small);
 }
 
-int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* zs, float* out,
-                         int64_t P, void* ws, size_t ws_bytes, void* stream) {
-  RPDE_CHECK_ARG(p && x && zs && out && P > 0, "feedforward_fwd: bad arguments");
+int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs,
+                         float* const* ds, float* z_last, float* out, int64_t P, void* ws, size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(p && x && z_last && out && P > 0, "feedforward_fwd: bad arguments");
   RPDE_CHECK_ARG(p->n_layers >= 1 && p->dim > 0 && p->factor > 0, "feedforward_fwd: bad shape");
+  RPDE_CHECK_ARG(p->n_layers == 1 || hs, "feedforward_fwd: hidden buffers missing");
   RPDE_CHECK_ARG(P < (1L << 31), "feedforward_fwd: too many points for one call");
   RPDE_CHECK_ARG(p->dropout_p >= 0.f && p->dropout_p < 1.f, "feedforward_fwd: dropout %f", p->dropout_p);
   hipStream_t st = as_stream(stream);
   (void)ws; (void)ws_bytes;
   const int L = p->n_layers;
   for (int l = 0; l < L; ++l) {
-    RPDE_CHECK_ARG(zs[l] && p->weights[l], "feedforward_fwd: null layer %d buffers", l);
-    const float* in = l == 0 ? x : zs[l - 1];
-    RPDE_TRY(linear_fwd_impl(in, p->weights[l], p->biases ? p->biases[l] : nullptr, zs[l], P, ff_in(p, l), ff_out(p, l),
-                             l == 0 ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU, l == 0 ? 0.f : p->dropout_p,
-                             layer_seed(p->seed, l - 1), st));
+    const bool last = l == L - 1;
+    RPDE_CHECK_ARG(p->weights[l] && (last || hs[l]), "feedforward_fwd: null layer %d buffers", l);
+    const float* in = l == 0 ? x : hs[l - 1];
+    RPDE_TRY(linear_fwd_impl(in, p->weights[l], p->biases ? p->biases[l] : nullptr, last ? z_last : hs[l], P, ff_in(p, l),
+                             ff_out(p, l), last ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU, (last || !ds) ? nullptr : ds[l],
+                             p->dropout_p, layer_seed(p->seed, l), st));
   }
-  return ff_tail_fwd(zs[L - 1], residual, out, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
+  return ff_tail_fwd(z_last, residual, out, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
                      make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, st);
 }
 
-int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* const* zs, const float* grad_out,
-                         float* grad_x, float* const* grad_weights, float* const* grad_biases, float* grad_gamma,
-                         float* grad_beta, int64_t P, void* ws, size_t ws_bytes, void* stream) {
-  RPDE_CHECK_ARG(p && x && zs && grad_out && P > 0, "feedforward_bwd: bad arguments");
+int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* const* hs, const float* const* ds,
+                         const float* z_last, const float* grad_out, float* grad_x, float* const* grad_weights,
+                         float* const* grad_biases, float* grad_gamma, float* grad_beta, int64_t P, void* ws,
+                         size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(p && x && z_last && grad_out && P > 0, "feedforward_bwd: bad arguments");
+  RPDE_CHECK_ARG(p->n_layers == 1 || (hs && ds), "feedforward_bwd: saved hidden tensors missing");
   RPDE_CHECK_ARG(P < (1L << 31), "feedforward_bwd: too many points for one call");
   hipStream_t st = as_stream(stream);
   const int L = p->n_layers;
@@ -160,23 +167,19 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   float* dz = buf0;
   float* other = buf1;
   int bias_done = 0;      // grad_biases[l] already produced by the kernel that produced dz_l
-  RPDE_TRY(ff_tail_bwd(zs[L - 1], grad_out, dz, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
+  RPDE_TRY(ff_tail_bwd(z_last, grad_out, dz, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
                        make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, grad_gamma, grad_beta,
                        grad_biases ? grad_biases[L - 1] : nullptr, &bias_done, small, st));
   for (int l = L - 1; l >= 0; --l) {
     const int in_f = ff_in(p, l), out_f = ff_out(p, l);
-    const float* in = l == 0 ? x : zs[l - 1];
-    const int act_in = l == 0 ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU;
-    const float dp = l == 0 ? 0.f : p->dropout_p;
-    const uint64_t sd = layer_seed(p->seed, l - 1);
+    const float* in = l == 0 ? x : hs[l - 1];
     float* gb = (grad_biases && !bias_done) ? grad_biases[l] : nullptr;
-    RPDE_TRY(linear_wgrad_impl(in, dz, grad_weights ? grad_weights[l] : nullptr, gb, P, in_f, out_f, act_in, dp, sd, slabs,
-                               small, st));
+    RPDE_TRY(linear_wgrad_impl(in, dz, grad_weights ? grad_weights[l] : nullptr, gb, P, in_f, out_f, slabs, small, st));
     bias_done = 0;
     if (l > 0) {
-      const bool fuse = grad_biases && can_fuse_colsum(dz, p->weights[l], other, zs[l - 1], P, in_f, out_f);
-      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, RPDE_ACT_GELU, zs[l - 1], dp, sd,
-                                 fuse ? small : nullptr, st));
+      RPDE_CHECK_ARG(ds[l - 1], "feedforward_bwd: derivative of layer %d was not saved", l - 1);
+      const bool fuse = grad_biases && can_fuse_colsum(dz, p->weights[l], other, ds[l - 1], P, in_f, out_f);
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, ds[l - 1], fuse ? small : nullptr, st));
       if (fuse) {
         RPDE_TRY(reduce_slabs_2pass(small, grad_biases[l - 1], in_f, (int)colsum_tiles(P), in_f,
                                     small + colsum_tiles(P) * in_f, st));
@@ -184,7 +187,7 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
       }
       float* t = dz; dz = other; other = t;
     } else if (grad_x) {
-      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, 0, nullptr, 0.f, 0, nullptr, st));
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, nullptr, nullptr, st));
     }
   }
   return RPDE_OK;
@@ -197,7 +200,7 @@ size_t rpde_linear_ws_bytes(int64_t P, int in_f, int out_f) {
 
 int rpde_linear_fwd(const float* x, const float* w, const float* b, float* out, int64_t P, int in_f, int out_f, void* stream) {
   RPDE_CHECK_ARG(x && w && out && P > 0 && in_f > 0 && out_f > 0 && P < (1L << 31), "linear_fwd: bad arguments");
-  return linear_fwd_impl(x, w, b, out, P, in_f, out_f, RPDE_ACT_IDENTITY, 0.f, 0, as_stream(stream));
+  return linear_fwd_impl(x, w, b, out, P, in_f, out_f, RPDE_ACT_IDENTITY, nullptr, 0.f, 0, as_stream(stream));
 }
 
 int rpde_linear_bwd(const float* x, const float* w, const float* grad_out, float* grad_x, float* grad_w, float* grad_b,
@@ -208,8 +211,8 @@ int rpde_linear_bwd(const float* x, const float* w, const float* grad_out, float
   float* slabs = ar.take(wgrad_ws_floats(P, in_f, out_f));
   float* small = ar.take(colsum_ws_floats(P, out_f));
   if (!ar.ok()) { set_error("linear_bwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
-  RPDE_TRY(linear_wgrad_impl(x, grad_out, grad_w, grad_b, P, in_f, out_f, RPDE_ACT_IDENTITY, 0.f, 0, slabs, small, st));
-  if (grad_x) RPDE_TRY(linear_dgrad_impl(grad_out, w, grad_x, P, in_f, out_f, 0, nullptr, 0.f, 0, nullptr, st));
+  RPDE_TRY(linear_wgrad_impl(x, grad_out, grad_w, grad_b, P, in_f, out_f, slabs, small, st));
+  if (grad_x) RPDE_TRY(linear_dgrad_impl(grad_out, w, grad_x, P, in_f, out_f, nullptr, nullptr, st));
   return RPDE_OK;
 }
 

@@ -3,7 +3,14 @@
 // layout in gemm_{nt,nn,tn,tt}.hip.
 #include "gemm_kernel.h"
 
+#include <stdlib.h>
+
 namespace rpde {
+
+int gemm_variant() {
+  static const int v = [] { const char* e = getenv("RPDE_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  return v;
+}
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -22,8 +29,8 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   g.sA1 = d.sA1; g.sA2 = d.sA2; g.sB1 = d.sB1; g.sB2 = d.sB2; g.sC1 = d.sC1; g.sC2 = d.sC2;
   g.ksplit = d.ksplit; g.sCk = d.sCk;
   int kchunk = (d.K + d.ksplit - 1) / d.ksplit;
-  kchunk = ((kchunk + BK - 1) / BK) * BK;
-  g.kchunk = kchunk > 0 ? kchunk : BK;
+  kchunk = ((kchunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
+  g.kchunk = kchunk > 0 ? kchunk : BK_MAX;
   g.alpha = d.alpha; g.accumulate = d.accumulate;
   g.bias = d.bias; g.bias_mode = d.bias ? d.bias_mode : 0;
   g.act_a = d.act_a; g.act_b = d.act_b; g.epi_dact = d.epi_dact; g.write_act = d.write_act;
@@ -60,6 +67,9 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
            (d.N % 4 == 0) && (!d.aux || (al16(d.aux) && d.ldaux % 4 == 0)) &&
            (!(d.bias && d.bias_mode == 1) || al16(d.bias)) && (!(g.drop.on() && (d.drop_where & 4)) || d.drop_ld % 4 == 0);
   g.colsum = d.colsum;
+  g.aux_out = d.aux_out;
+  RPDE_CHECK_ARG(!d.aux_out || d.write_act, "gemm: aux_out needs write_act");
+  if (d.aux_out) g.cvec = g.cvec && al16(d.aux_out);
   RPDE_CHECK_ARG(!d.colsum || (g.cvec && BMc == 128 && d.batch == 1 && d.ksplit == 1),
                  "gemm: colsum needs the vector epilogue, M > 64 and a single un-split problem");
 

@@ -39,8 +39,8 @@ namespace rpde {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
 constexpr int NTHREADS = 256;
+constexpr int BK_MAX = 32;     // host-side K-slice rounding (every kernel BK divides it)
 
 struct GemmK {
   const float* A; const float* B; float* C;
@@ -57,9 +57,10 @@ struct GemmK {
   int mtiles, ntiles, swz;
   int cvec;          // C / aux / bias allow 16-byte row accesses: LDS-staged epilogue
   float* colsum;     // optional [mtiles][N] per-M-tile column sums of the stored C
+  float* aux_out;    // optional act'(u)*dropscale beside C = act(u)
 };
 
-template <int ROWS, bool KMAJOR, bool VEC, bool PRO>
+template <int ROWS, int BK, bool KMAJOR, bool VEC, bool PRO>
 struct Tile {
   static constexpr int NV = ROWS * BK / 4 / NTHREADS;          // float4 per thread
   static constexpr int LDK = BK + 4;                           // k-major row stride
@@ -67,7 +68,7 @@ struct Tile {
   static_assert(NV >= 1, "tile too small for 256 threads");
 
   __device__ __forceinline__ static void coords(int v, int& rr, int& kk) {
-    if (KMAJOR) { rr = v >> 3; kk = (v & 7) << 2; }
+    if (KMAJOR) { rr = v / (BK / 4); kk = (v % (BK / 4)) << 2; }
     else { kk = v / (ROWS / 4); rr = (v % (ROWS / 4)) << 2; }
   }
 
@@ -81,11 +82,13 @@ struct Tile {
       const int gr = r0 + rr, gk = k0 + kk;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (VEC) {
-        // host guarantees: extent along the contiguous index is a multiple of 4 and 16-byte aligned
-        if (gr < rmax && gk < kend) {
-          const float* p = KMAJOR ? base + (long)gr * ld + gk : base + (long)gk * ld + gr;
-          val = *reinterpret_cast<const float4*>(p);
-        }
+        // host guarantees: extent along the contiguous index is a multiple of 4 and 16-byte aligned.
+        // Branch-free: out-of-range lanes read the (valid) base address and are zeroed by a select,
+        // so the loads stay in one basic block and the compiler can use counted vmcnt waits.
+        const bool ok = gr < rmax && gk < kend;
+        const long off = KMAJOR ? (long)gr * ld + gk : (long)gk * ld + gr;
+        const float4 t = *reinterpret_cast<const float4*>(base + (ok ? off : 0L));
+        val.x = ok ? t.x : 0.f; val.y = ok ? t.y : 0.f; val.z = ok ? t.z : 0.f; val.w = ok ? t.w : 0.f;
       } else if (gr < rmax && gk < kend) {
         if (KMAJOR) {
           const float* p = base + (long)gr * ld + gk;
@@ -105,11 +108,15 @@ struct Tile {
     }
   }
 
-  // registers -> LDS, applying h = act(dropout(z)) when this operand is the activated one
+  // registers -> LDS, applying h = act(dropout(z)) when this operand is the activated one.
+  // PART/NPARTS: only the vectors i with i % NPARTS == PART (the k-loop spreads the staging of the next
+  // tile between the MFMA groups of the current one)
+  template <int PART = 0, int NPARTS = 1>
   __device__ __forceinline__ static void store(float* __restrict__ lds, const float4 (&r)[NV], int tid, int act,
                                                bool use_drop, const DropCfg& drop, long drop_ld, int r0, int k0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+      if (i % NPARTS != PART) continue;
       int rr, kk;
       coords(tid + i * NTHREADS, rr, kk);
       float4 v = r[i];
@@ -150,18 +157,25 @@ struct Tile {
   }
 };
 
-// PRO: 0 no staged activation, 1 on A, 2 on B
-template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PRO, bool VEC>
+// PRO: 0 no staged activation, 1 on A, 2 on B.  BK: k-extent of a stage; STAGES: LDS stages (2 = double
+// buffered, one barrier per stage; 1 = single buffer, two barriers, half the LDS -> more resident waves)
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PRO, bool VEC, int BK = 32, int STAGES = 2, bool PIPE = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
-  using TA = Tile<BM, AK, VEC, PRO == 1>;
-  using TB = Tile<BN, BKM, VEC, PRO == 2>;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (TA::LDS_FLOATS + TB::LDS_FLOATS)];
+  using TA = Tile<BM, BK, AK, VEC, PRO == 1>;
+  using TB = Tile<BN, BK, BKM, VEC, PRO == 2>;
+  constexpr int STAGE_FLOATS = TA::LDS_FLOATS + TB::LDS_FLOATS;
+  constexpr int SMEM_FLOATS = STAGES * STAGE_FLOATS;
+  // the epilogue stages the C tile through the same LDS in EP row-slabs
+  constexpr int EP = (BM * BN + SMEM_FLOATS - 1) / SMEM_FLOATS;
+  static_assert(EP == 1 || EP == 2 || EP == 4, "C tile needs too many epilogue passes");
+  static_assert((BM / 32) % EP == 0, "epilogue slabs must be whole 32-row tiles");
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* const As0 = smem;
-  float* const As1 = smem + TA::LDS_FLOATS;
-  float* const Bs0 = smem + 2 * TA::LDS_FLOATS;
-  float* const Bs1 = Bs0 + TB::LDS_FLOATS;
+  float* const As1 = STAGES == 2 ? smem + TA::LDS_FLOATS : smem;
+  float* const Bs0 = smem + STAGES * TA::LDS_FLOATS;
+  float* const Bs1 = STAGES == 2 ? Bs0 + TB::LDS_FLOATS : Bs0;
 
   const int tid = threadIdx.x;
   // ---- which tile, which batch entry, which K slice -------------------------
@@ -203,44 +217,109 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
   const bool drop_a = g.drop.on() && (g.drop_where & 1);
   const bool drop_b = g.drop.on() && (g.drop_where & 2);
   const bool drop_e = g.drop.on() && (g.drop_where & 4);
-  float4 ra[TA::NV], rb[TB::NV];
+  // ---- main loop (PIPE = false): register prefetch one tile ahead, stage after the MFMA block ----
+  if constexpr (!PIPE) {
+    float4 ra[TA::NV], rb[TB::NV];
+    if (nkt > 0) {
+      TA::load(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
+      TB::load(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
+      TA::store(As0, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, kbeg);
+      TB::store(Bs0, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, kbeg);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const float* as = (kt & 1) ? As1 : As0;
+      const float* bs = (kt & 1) ? Bs1 : Bs0;
+      const bool more = kt + 1 < nkt;
+      const int knext = kbeg + (kt + 1) * BK;
+      if (more) {  // issue the next stage's HBM loads before computing this one
+        TA::load(ra, A, g.lda, m0, g.M, knext, kend, tid);
+        TB::load(rb, B, g.ldb, n0, g.N, knext, kend, tid);
+      }
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        float af[TM][4], bf[TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) TA::frag(as, (wm * TM + i) * 32 + l31, lh, q, af[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) TB::frag(bs, (wn * TN + j) * 32 + l31, lh, q, bf[j]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+      }
+      if (STAGES == 1) __syncthreads();
+      if (more) {
+        TA::store((kt & 1) ? As0 : As1, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);
+        TB::store((kt & 1) ? Bs0 : Bs1, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext);
+      }
+      __syncthreads();
+    }
+  } else {
+  // ---- main loop, software-pipelined two tiles deep ---------------------------------------------
+  // tile t lives in register set t&1 and LDS stage t&1.  Iteration kt: issue the HBM loads of tile kt+2
+  // (into the set that held tile kt), run the MFMAs of tile kt from LDS, and between the MFMA groups
+  // stage tile kt+1 (activation + LDS writes) from the other set -- its loads were issued a whole
+  // iteration ago, and its VALU work hides under this tile's 64-cycle MFMAs.
+  float4 ra0[TA::NV], rb0[TB::NV], ra1[TA::NV], rb1[TB::NV];
+  constexpr int NQ = BK / 8;        // MFMA groups (4 k-steps each) per tile
   if (nkt > 0) {
-    TA::load(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
-    TB::load(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
-    TA::store(As0, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, kbeg);
-    TB::store(Bs0, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, kbeg);
+    TA::load(ra0, A, g.lda, m0, g.M, kbeg, kend, tid);
+    TB::load(rb0, B, g.ldb, n0, g.N, kbeg, kend, tid);
+    TA::load(ra1, A, g.lda, m0, g.M, kbeg + BK, kend, tid);
+    TB::load(rb1, B, g.ldb, n0, g.N, kbeg + BK, kend, tid);
+    TA::store(As0, ra0, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, kbeg);
+    TB::store(Bs0, rb0, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, kbeg);
   }
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const float* as = (kt & 1) ? As1 : As0;
-    const float* bs = (kt & 1) ? Bs1 : Bs0;
-    const bool more = kt + 1 < nkt;
-    const int knext = kbeg + (kt + 1) * BK;
-    if (more) {  // issue the next stage's HBM loads before computing this one
-      TA::load(ra, A, g.lda, m0, g.M, knext, kend, tid);
-      TB::load(rb, B, g.ldb, n0, g.N, knext, kend, tid);
-    }
-#pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      float af[TM][4], bf[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) TA::frag(as, (wm * TM + i) * 32 + l31, lh, q, af[i]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) TB::frag(bs, (wn * TN + j) * 32 + l31, lh, q, bf[j]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      TA::store((kt & 1) ? As0 : As1, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);
-      TB::store((kt & 1) ? Bs0 : Bs1, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext);
-    }
-    __syncthreads();
+#define RPDE_GEMM_STEP(RA_FREE, RB_FREE, RA_NEXT, RB_NEXT, AS_CUR, BS_CUR, AS_NEXT, BS_NEXT)                          \
+  {                                                                                                                 \
+    const bool more = kt + 1 < nkt;                                                                                 \
+    const int knext = kbeg + (kt + 1) * BK;                                                                         \
+    /* unconditional: past the end the loads are predicated to the base address (VEC) -> countable vmcnt */       \
+    TA::load(RA_FREE, A, g.lda, m0, g.M, knext + BK, kend, tid);                                                    \
+    TB::load(RB_FREE, B, g.ldb, n0, g.N, knext + BK, kend, tid);                                                    \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                                \
+      float af[TM][4], bf[TN][4];                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) TA::frag(AS_CUR, (wm * TM + i) * 32 + l31, lh, q, af[i]);      \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) TB::frag(BS_CUR, (wn * TN + j) * 32 + l31, lh, q, bf[j]);      \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                              \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                            \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);               \
+      if (STAGES == 2 && more) {                                                                                    \
+        if (q == 0) { TA::template store<0, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);   \
+                      TB::template store<0, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext); } \
+        if (q == 1) { TA::template store<1, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);   \
+                      TB::template store<1, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext); } \
+        if (NQ > 2 && q == 2) { TA::template store<2 % NQ, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);   \
+                      TB::template store<2 % NQ, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext); } \
+        if (NQ > 3 && q == 3) { TA::template store<3 % NQ, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);   \
+                      TB::template store<3 % NQ, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext); } \
+      }                                                                                                             \
+    }                                                                                                               \
+    if (STAGES == 1) {                                                                                              \
+      __syncthreads();                                                                                              \
+      if (more) {                                                                                                   \
+        TA::store(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);                            \
+        TB::store(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext);                            \
+      }                                                                                                             \
+    }                                                                                                               \
+    __syncthreads();                                                                                                \
+  }
+
+  for (int kt = 0; kt < nkt;) {
+    RPDE_GEMM_STEP(ra0, rb0, ra1, rb1, As0, Bs0, As1, Bs1)      // even tile: compute stage 0, stage tile kt+1 from set 1
+    if (++kt >= nkt) break;
+    RPDE_GEMM_STEP(ra1, rb1, ra0, rb0, As1, Bs1, As0, Bs0)      // odd tile
+    ++kt;
+  }
+#undef RPDE_GEMM_STEP
+
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -249,54 +328,74 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
     // last barrier) so that HBM sees whole 16-byte vectors of contiguous rows:
     // 4x fewer store / aux-load instructions, one dropout hash per 4 elements,
     // and the per-tile column sums (bias gradients) come for free.
-    static_assert(BM * BN <= 2 * (TA::LDS_FLOATS + TB::LDS_FLOATS), "C tile must fit the operand staging buffers");
     float* __restrict__ cs = smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 32 + l31;
-        const int rb = (wm * TM + i) * 32 + 4 * lh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * BN + col] = acc[i][j][r];
-      }
-    __syncthreads();
+    constexpr int SLAB = BM / EP;                     // rows per epilogue pass
     constexpr int VPR = BN / 4;                       // vectors per tile row
-    constexpr int NV4 = BM * BN / 4 / NTHREADS;       // vectors per thread
+    constexpr int NV4 = SLAB * BN / 4 / NTHREADS;     // vectors per thread per pass
     constexpr int RSTEP = NTHREADS / VPR;             // rows between a thread's vectors
+    static_assert(NV4 >= 1, "epilogue slab too small");
     const int c4 = (tid % VPR) * 4, row0 = tid / VPR;
     const int gn = n0 + c4;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gn < g.N) {
-      float4 bn4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias_mode == 1) bn4 = *reinterpret_cast<const float4*>(g.bias + gn);
-      const float* __restrict__ aux = g.aux ? g.aux + coff : nullptr;
+    float4 bn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias_mode == 1 && gn < g.N) bn4 = *reinterpret_cast<const float4*>(g.bias + gn);
+    const float* __restrict__ aux = g.aux ? g.aux + coff : nullptr;
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+      if (e > 0) __syncthreads();                     // previous slab fully consumed
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int rt = (wm * TM + i) * 32;            // first row of this 32-row tile inside the block
+        if (rt / SLAB != e) continue;                 // wave-uniform
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = (wn * TN + j) * 32 + l31;
+          const int rb = rt - e * SLAB + 4 * lh;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cs[(rb + (r & 3) + 8 * (r >> 2)) * BN + col] = acc[i][j][r];
+        }
+      }
+      __syncthreads();
+      if (gn < g.N) {
 #pragma unroll 4
-      for (int it = 0; it < NV4; ++it) {
-        const int row = row0 + it * RSTEP;
-        const int gm = m0 + row;
-        if (gm >= g.M) break;
-        float4 v = *reinterpret_cast<const float4*>(cs + row * BN + c4);
-        v.x = fmaf(v.x, g.alpha, bn4.x); v.y = fmaf(v.y, g.alpha, bn4.y);
-        v.z = fmaf(v.z, g.alpha, bn4.z); v.w = fmaf(v.w, g.alpha, bn4.w);
-        if (g.bias_mode == 2) { const float bm = g.bias[gm]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
-        if (g.epi_dact) {
-          float s[4] = {1.f, 1.f, 1.f, 1.f};
-          if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
-          const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
-          v.x *= dact_f(g.epi_dact, a.x * s[0]) * s[0];
-          v.y *= dact_f(g.epi_dact, a.y * s[1]) * s[1];
-          v.z *= dact_f(g.epi_dact, a.z * s[2]) * s[2];
-          v.w *= dact_f(g.epi_dact, a.w * s[3]) * s[3];
+        for (int it = 0; it < NV4; ++it) {
+          const int row = row0 + it * RSTEP;
+          const int gm = m0 + e * SLAB + row;
+          if (gm >= g.M) break;
+          float4 v = *reinterpret_cast<const float4*>(cs + row * BN + c4);
+          v.x = fmaf(v.x, g.alpha, bn4.x); v.y = fmaf(v.y, g.alpha, bn4.y);
+          v.z = fmaf(v.z, g.alpha, bn4.z); v.w = fmaf(v.w, g.alpha, bn4.w);
+          if (g.bias_mode == 2) { const float bm = g.bias[gm]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+          if (g.epi_dact == RPDE_EPI_MULAUX) {
+            const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
+            v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
+          } else if (g.epi_dact) {
+            float s[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+            const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
+            v.x *= dact_f(g.epi_dact, a.x * s[0]) * s[0];
+            v.y *= dact_f(g.epi_dact, a.y * s[1]) * s[1];
+            v.z *= dact_f(g.epi_dact, a.z * s[2]) * s[2];
+            v.w *= dact_f(g.epi_dact, a.w * s[3]) * s[3];
+          }
+          float4* cp = reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn);
+          if (g.accumulate) { const float4 o = *cp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          if (g.write_act) {
+            float s[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop_e && !g.epi_dact) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+            v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
+            if (g.aux_out) {
+              float4 dv;
+              dv.x = dact_f(g.write_act, v.x) * s[0]; dv.y = dact_f(g.write_act, v.y) * s[1];
+              dv.z = dact_f(g.write_act, v.z) * s[2]; dv.w = dact_f(g.write_act, v.w) * s[3];
+              *reinterpret_cast<float4*>(g.aux_out + coff + (long)gm * g.ldc + gn) = dv;
+            }
+            v.x = act_f(g.write_act, v.x); v.y = act_f(g.write_act, v.y);
+            v.z = act_f(g.write_act, v.z); v.w = act_f(g.write_act, v.w);
+          }
+          *cp = v;
+          csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
         }
-        float4* cp = reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn);
-        if (g.accumulate) { const float4 o = *cp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        if (g.write_act) {
-          v.x = act_f(g.write_act, v.x); v.y = act_f(g.write_act, v.y);
-          v.z = act_f(g.write_act, v.z); v.w = act_f(g.write_act, v.w);
-        }
-        *cp = v;
-        csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
       }
     }
     if (g.colsum) {      // uniform
@@ -332,14 +431,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
         float v = fmaf(acc[i][j][r], g.alpha, bn);
         if (g.bias_mode == 2) v += g.bias[mb + dm];
         if (!plain) {
-          if (g.epi_dact) {
+          if (g.epi_dact == RPDE_EPI_MULAUX) {
+            v *= ab[dm * g.ldaux];
+          } else if (g.epi_dact) {
             float s = 1.f;
             if (drop_e) s = drop_scale1(g.drop, idb + (uint64_t)(dm * g.drop_ld));
             const float u = ab[dm * g.ldaux] * s;
             v = v * dact_f(g.epi_dact, u) * s;
           }
           if (g.accumulate) v += cb[dm * ldc];
-          if (g.write_act) v = act_f(g.write_act, v);
+          if (g.write_act) {
+            float s = 1.f;
+            if (drop_e && !g.epi_dact) s = drop_scale1(g.drop, idb + (uint64_t)(dm * g.drop_ld));
+            v *= s;
+            if (g.aux_out) g.aux_out[coff + (long)(mb + dm) * ldc + n] = dact_f(g.write_act, v) * s;
+            v = act_f(g.write_act, v);
+          }
         }
         cb[dm * ldc] = v;
       }
@@ -350,19 +457,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
 // ---- host-side dispatch, instantiated once per operand layout (one translation
 // unit each, so the instantiations compile in parallel).  PM: bit p set <=> the
 // staged-activation variant PRO = p is built for this layout.
-template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PM, bool VEC>
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PM, bool VEC, int BK = 32, int STAGES = 2, bool PIPE = false>
 inline void launch_pro(const GemmK& g, int pro, dim3 grid, hipStream_t st) {
   if (pro == 0) {
     if constexpr ((PM & 1) != 0)
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 0, VEC>), grid, dim3(NTHREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 0, VEC, BK, STAGES, PIPE>), grid, dim3(NTHREADS), 0, st, g);
   } else if (pro == 1) {
     if constexpr ((PM & 2) != 0)
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 1, VEC>), grid, dim3(NTHREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 1, VEC, BK, STAGES, PIPE>), grid, dim3(NTHREADS), 0, st, g);
   } else {
     if constexpr ((PM & 4) != 0)
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 2, VEC>), grid, dim3(NTHREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 2, VEC, BK, STAGES, PIPE>), grid, dim3(NTHREADS), 0, st, g);
   }
 }
+
+int gemm_variant();   // experiment switch (env RPDE_GEMM_VARIANT) for the 128 x 128 tile
 
 template <bool AK, bool BKM, int PM>
 inline int launch_layout_impl(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st) {
@@ -370,12 +479,26 @@ inline int launch_layout_impl(const GemmK& g, int bm, int bn, int pro, bool vec,
     set_error("gemm: staged activation on operand %d is not built for layout a_kmajor=%d b_kmajor=%d", pro, (int)AK, (int)BKM);
     return RPDE_ERR_ARG;
   }
+  // RPDE_GEMM_VARIANT (A/B experiments, same-box numbers in profiles/r01_c_gemm_variants.txt):
+  //   0 default: two-deep software pipeline on every vector tile;  1: lean loop on the small tiles;
+  //   2: lean loop everywhere.  (Smaller-LDS variants -- BK16 x 2, BK32 x 1 -- were within 2 %: the
+  //   resident-wave count is not what limits this kernel.)
+  const int v = gemm_variant();
+  const bool pipe_big = v != 2, pipe_small = v == 0;
   if (!vec) launch_pro<2, 2, 1, 1, AK, BKM, PM, false>(g, pro, grid, st);            // 64 x 64, scalar loads
-  else if (bm == 128 && bn == 128) launch_pro<2, 2, 2, 2, AK, BKM, PM, true>(g, pro, grid, st);
-  else if (bm == 128 && bn == 64) launch_pro<4, 1, 1, 2, AK, BKM, PM, true>(g, pro, grid, st);
-  else if (bm == 64 && bn == 128) launch_pro<1, 4, 2, 1, AK, BKM, PM, true>(g, pro, grid, st);
-  else if (bm == 64 && bn == 64) launch_pro<2, 2, 1, 1, AK, BKM, PM, true>(g, pro, grid, st);
-  else if (bm == 128 && bn == 32) launch_pro<4, 1, 1, 1, AK, BKM, PM, true>(g, pro, grid, st);
+  else if (bm == 128 && bn == 128) {
+    if (pipe_big) launch_pro<2, 2, 2, 2, AK, BKM, PM, true, 32, 2, true>(g, pro, grid, st);
+    else launch_pro<2, 2, 2, 2, AK, BKM, PM, true>(g, pro, grid, st);
+  } else if (bm == 128 && bn == 64) {
+    if (pipe_small) launch_pro<4, 1, 1, 2, AK, BKM, PM, true, 32, 2, true>(g, pro, grid, st);
+    else launch_pro<4, 1, 1, 2, AK, BKM, PM, true>(g, pro, grid, st);
+  } else if (bm == 64 && bn == 128) {
+    if (pipe_small) launch_pro<1, 4, 2, 1, AK, BKM, PM, true, 32, 2, true>(g, pro, grid, st);
+    else launch_pro<1, 4, 2, 1, AK, BKM, PM, true>(g, pro, grid, st);
+  } else if (bm == 64 && bn == 64) {
+    if (pipe_small) launch_pro<2, 2, 1, 1, AK, BKM, PM, true, 32, 2, true>(g, pro, grid, st);
+    else launch_pro<2, 2, 1, 1, AK, BKM, PM, true>(g, pro, grid, st);
+  } else if (bm == 128 && bn == 32) launch_pro<4, 1, 1, 1, AK, BKM, PM, true>(g, pro, grid, st);
   else launch_pro<1, 4, 1, 1, AK, BKM, PM, true>(g, pro, grid, st);                   // 32 x 128
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;

@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64),
         ("write_act", C.c_int), ("drop_where", C.c_int),
-        ("colsum", C.c_void_p),
+        ("colsum", C.c_void_p), ("aux_out", C.c_void_p),
     ]
 
 
@@ -86,8 +86,8 @@ _SIGNATURES = {
     "rpde_spectral2d_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_spectral2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_feedforward_ws_bytes": (_Z, [_L, _I, _I, _I]),
-    "rpde_feedforward_fwd": (_I, [C.POINTER(FFParams), _P, _P, _PP, _P, _L, _P, _Z, _P]),
-    "rpde_feedforward_bwd": (_I, [C.POINTER(FFParams), _P, _PP, _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
+    "rpde_feedforward_fwd": (_I, [C.POINTER(FFParams), _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
+    "rpde_feedforward_bwd": (_I, [C.POINTER(FFParams), _P, _PP, _PP, _P, _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
     "rpde_linear_ws_bytes": (_Z, [_L, _I, _I]),
     "rpde_linear_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
     "rpde_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _Z, _P]),

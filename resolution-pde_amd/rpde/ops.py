@@ -142,16 +142,22 @@ class _FeedForward(torch.autograd.Function):
         bs_ = [_f32c(params[2 * l + 1]) for l in range(L)]
         gamma = _f32c(params[2 * L]) if layer_norm else None
         beta = _f32c(params[2 * L + 1]) if layer_norm else None
-        zs = [torch.empty(P, dim if l == L - 1 else dim * factor, dtype=torch.float32, device=x.device) for l in range(L)]
+        need_grad = any(ctx.needs_input_grad)
+        hid = dim * factor
+        hs = [torch.empty(P, hid, dtype=torch.float32, device=x.device) for _ in range(L - 1)]
+        ds = [torch.empty(P, hid, dtype=torch.float32, device=x.device) if need_grad else None for _ in range(L - 1)]
+        z_last = torch.empty(P, dim, dtype=torch.float32, device=x.device)
         out = torch.empty(P, dim, dtype=torch.float32, device=x.device)
-        wa, ba, za = ptr_array(ws_), ptr_array(bs_), ptr_array(zs)
+        wa, ba, ha, da = ptr_array(ws_), ptr_array(bs_), ptr_array(hs or [None]), ptr_array(ds or [None])
         fp = _lib.FFParams(L, dim, factor, int(layer_norm), eps, p_drop, seed, post_act,
                            C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta))
-        check(lib.rpde_feedforward_fwd(C.byref(fp), ptr(x2), ptr(res2), C.cast(za, C.POINTER(C.c_void_p)), ptr(out), P,
-                                       None, 0, stream_ptr()), "feedforward_fwd")
+        check(lib.rpde_feedforward_fwd(C.byref(fp), ptr(x2), ptr(res2), C.cast(ha, C.POINTER(C.c_void_p)),
+                                       C.cast(da, C.POINTER(C.c_void_p)), ptr(z_last), ptr(out), P, None, 0,
+                                       stream_ptr()), "feedforward_fwd")
         ctx.cfg = cfg
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x2, *zs, *ws_, *bs_, *([gamma, beta] if layer_norm else []))
+        if need_grad:
+            ctx.save_for_backward(x2, z_last, *hs, *ds, *ws_, *bs_, *([gamma, beta] if layer_norm else []))
         return out.reshape(shape)
 
     @staticmethod
@@ -159,9 +165,12 @@ class _FeedForward(torch.autograd.Function):
         lib = load()
         L, dim, factor, layer_norm, eps, p_drop, seed, post_act = ctx.cfg
         saved = ctx.saved_tensors
-        x2, zs = saved[0], list(saved[1:1 + L])
-        ws_, bs_ = list(saved[1 + L:1 + 2 * L]), list(saved[1 + 2 * L:1 + 3 * L])
-        gamma, beta = (saved[1 + 3 * L], saved[2 + 3 * L]) if layer_norm else (None, None)
+        x2, z_last = saved[0], saved[1]
+        o = 2
+        hs, ds = list(saved[o:o + L - 1]), list(saved[o + L - 1:o + 2 * (L - 1)])
+        o += 2 * (L - 1)
+        ws_, bs_ = list(saved[o:o + L]), list(saved[o + L:o + 2 * L])
+        gamma, beta = (saved[o + 2 * L], saved[o + 2 * L + 1]) if layer_norm else (None, None)
         P = x2.shape[0]
         g2 = _f32c(g).reshape(-1, dim)
         gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
@@ -169,13 +178,14 @@ class _FeedForward(torch.autograd.Function):
         gbs = [torch.empty_like(b) for b in bs_]
         ggamma = torch.empty_like(gamma) if layer_norm else None
         gbeta = torch.empty_like(beta) if layer_norm else None
-        wa, ba, za = ptr_array(ws_), ptr_array(bs_), ptr_array(zs)
+        wa, ba, ha, da = ptr_array(ws_), ptr_array(bs_), ptr_array(hs or [None]), ptr_array(ds or [None])
         gwa, gba = ptr_array(gws), ptr_array(gbs)
         fp = _lib.FFParams(L, dim, factor, int(layer_norm), eps, p_drop, seed, post_act,
                            C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta))
         nws = lib.rpde_feedforward_ws_bytes(P, dim, factor, L)
         ws = workspace(nws, g.device)
-        check(lib.rpde_feedforward_bwd(C.byref(fp), ptr(x2), C.cast(za, C.POINTER(C.c_void_p)), ptr(g2), ptr(gx),
+        check(lib.rpde_feedforward_bwd(C.byref(fp), ptr(x2), C.cast(ha, C.POINTER(C.c_void_p)),
+                                       C.cast(da, C.POINTER(C.c_void_p)), ptr(z_last), ptr(g2), ptr(gx),
                                        C.cast(gwa, C.POINTER(C.c_void_p)), C.cast(gba, C.POINTER(C.c_void_p)),
                                        ptr(ggamma), ptr(gbeta), P, ws.data_ptr(), nws, stream_ptr()), "feedforward_bwd")
         grads: List[Optional[torch.Tensor]] = []
