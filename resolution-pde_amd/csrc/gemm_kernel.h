@@ -487,7 +487,10 @@ inline int launch_layout_impl(const GemmK& g, int bm, int bn, int pro, bool vec,
   const bool pipe_big = v != 2, pipe_small = v == 0;
   if (!vec) launch_pro<2, 2, 1, 1, AK, BKM, PM, false>(g, pro, grid, st);            // 64 x 64, scalar loads
   else if (bm == 128 && bn == 128) {
-    if (pipe_big) launch_pro<2, 2, 2, 2, AK, BKM, PM, true, 32, 2, true>(g, pro, grid, st);
+    // reductions of <= 2 stages are epilogue / HBM-latency bound: lean single-stage kernel (~90 VGPRs,
+    // 37 KB LDS -> 4 workgroups per CU) keeps more memory requests in flight  (variant 3 disables)
+    if (g.kchunk <= 64 && v != 3 && v != 2) launch_pro<2, 2, 2, 2, AK, BKM, PM, true, 32, 1, false>(g, pro, grid, st);
+    else if (pipe_big) launch_pro<2, 2, 2, 2, AK, BKM, PM, true, 32, 2, true>(g, pro, grid, st);
     else launch_pro<2, 2, 2, 2, AK, BKM, PM, true>(g, pro, grid, st);
   } else if (bm == 128 && bn == 64) {
     if (pipe_small) launch_pro<4, 1, 1, 2, AK, BKM, PM, true, 32, 2, true>(g, pro, grid, st);

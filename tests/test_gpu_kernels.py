@@ -166,3 +166,50 @@ def test_cpu_tensor_is_rejected_loudly(gpu_device):
     from rpde import RpdeError, ops
     with pytest.raises(RpdeError):
         ops.relative_l2(torch.randn(2, 8), torch.randn(2, 8))
+
+
+def test_gemm_writes_activation_and_derivative_once(gpu_device):
+    """write_act + aux_out: C = gelu(dropout(acc+bias)), aux_out = gelu'(dropout(.)) * scale; a second GEMM
+    with RPDE_EPI_MULAUX multiplies by that stored derivative; column sums of the stored C come with it."""
+    from rpde import _lib
+    lib = _lib.load()
+    P, N, K, p, seed = 640, 256, 64, 0.2, 99
+    g = torch.Generator().manual_seed(5)
+    X, W, b = torch.randn(P, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
+    Xd, Wd, bd = X.to(gpu_device), W.to(gpu_device), b.to(gpu_device)
+    h, dd = torch.empty(P, N, device=gpu_device), torch.empty(P, N, device=gpu_device)
+    cs = torch.empty((P + 127) // 128, N, device=gpu_device)
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = Xd.data_ptr(), Wd.data_ptr(), h.data_ptr()
+    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = P, N, K, 1, 1
+    d.lda, d.ldb, d.ldc, d.batch, d.zdiv, d.ksplit, d.alpha = K, K, N, 1, 1, 1, 1.0
+    d.bias, d.bias_mode, d.write_act, d.aux_out, d.colsum = bd.data_ptr(), 1, 1, dd.data_ptr(), cs.data_ptr()
+    d.drop_p, d.drop_seed, d.drop_ld, d.drop_where = p, seed, N, 4
+    _lib.check(lib.rpde_gemm_f32(C.byref(d), _lib.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    z = X.double() @ W.double().T + b.double()
+    hh, dv = h.cpu().double(), dd.cpu().double()
+    keep = dv != 0                                   # gelu' is never exactly 0 where kept (|z| is moderate here)
+    frac = 1 - keep.double().mean().item()
+    assert abs(frac - p) < 0.02, frac
+    scale = 1 / (1 - round(p * 65536) / 65536)
+    zr = (z * scale * keep).requires_grad_(True)
+    ref_h = torch.nn.functional.gelu(zr)
+    ref_h.sum().backward()
+    assert float((hh - ref_h.detach()).norm() / ref_h.detach().norm()) < 2e-6
+    ref_d = zr.grad * scale * keep
+    assert float((dv - ref_d).norm() / ref_d.norm()) < 2e-6
+    assert float((cs.cpu().double().sum(0) - hh.sum(0)).abs().max()) < 1e-3
+    # backward-data through the stored derivative: gx = (G @ W2) * d
+    G = torch.randn(P, 96, generator=g)
+    W2 = torch.randn(96, N, generator=g)
+    Gd, W2d = G.to(gpu_device), W2.to(gpu_device)
+    gx = torch.empty(P, N, device=gpu_device)
+    e = _lib.GemmDesc()
+    e.A, e.B, e.C = Gd.data_ptr(), W2d.data_ptr(), gx.data_ptr()
+    e.M, e.N, e.K, e.a_kmajor, e.b_kmajor = P, N, 96, 1, 0
+    e.lda, e.ldb, e.ldc, e.batch, e.zdiv, e.ksplit, e.alpha = 96, N, N, 1, 1, 1, 1.0
+    e.epi_dact, e.aux, e.ldaux = 100, dd.data_ptr(), N
+    _lib.check(lib.rpde_gemm_f32(C.byref(e), _lib.stream_ptr()), "gemm")
+    ref = (G.double() @ W2.double()) * dv
+    assert float((gx.cpu().double() - ref).norm() / ref.norm()) < 2e-6
