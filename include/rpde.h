@@ -218,6 +218,17 @@ int rpde_concat_grid(const float* x, float* out, int B, int Cin, int M, int N /*
 /* [B,S,C] <-> [B,C,S] */
 int rpde_transpose_cs(const float* in, float* out, int B, int64_t S, int C, int to_channels_first, void* stream);
 
+/* ---- spectral resize: rfft -> shared bins -> irfft at the new size, x out/in
+ * (reference: utils/res_utils.py:29-50 `resize`, :93-125 `resize_1d`; used by the
+ * all-resolution evaluators, utils/naive_utils.py, utils/resize_utils.py).
+ * x [rows, n_in] -> out [rows, n_out];  x [rows, M, N] -> out [rows, Mo, No]. */
+size_t rpde_resize1d_ws_bytes(int64_t rows, int n_in, int n_out);
+int rpde_resize1d(const float* x, float* out, int64_t rows, int n_in, int n_out,
+                  void* ws, size_t ws_bytes, void* stream);
+size_t rpde_resize2d_ws_bytes(int64_t rows, int M, int N, int Mo, int No);
+int rpde_resize2d(const float* x, float* out, int64_t rows, int M, int N, int Mo, int No,
+                  void* ws, size_t ws_bytes, void* stream);
+
 /* ---- elementwise activation: out = act(x); backward dx = g * act'(x) */
 int rpde_act_fwd(const float* x, float* out, int64_t n, int act, void* stream);
 int rpde_act_bwd(const float* x, const float* g, float* dx, int64_t n, int act, void* stream);

@@ -260,6 +260,31 @@ def relative_l2(x: Tensor, y: Tensor, size_average: bool = True, reduction: bool
 
 
 # --------------------------------------------------------------------------
+# spectral resize  (utils/res_utils.py:93-125 resize_1d, :29-50 resize)
+# --------------------------------------------------------------------------
+def resize_1d(x: Tensor, out_size: int) -> Tensor:
+    n = x.shape[-1]
+    f = torch.fft.rfft(x, norm="backward")
+    fz = torch.zeros((*x.shape[:-1], out_size // 2 + 1), dtype=f.dtype)
+    k = min(f.shape[-1], out_size // 2 + 1)
+    fz[..., :k] = f[..., :k]
+    return torch.fft.irfft(fz, n=out_size) * (out_size / n)
+
+
+def resize_2d(x: Tensor, out_size) -> Tensor:
+    m, n = x.shape[-2], x.shape[-1]
+    mo, no = out_size
+    f = torch.fft.rfft2(x, norm="backward")
+    fz = torch.zeros((*x.shape[:-2], mo, no // 2 + 1), dtype=f.dtype)
+    top1, bot1 = min((m + 1) // 2, (mo + 1) // 2), min(m // 2, mo // 2)
+    k2 = min(f.shape[-1], no // 2 + 1)
+    fz[..., :top1, :k2] = f[..., :top1, :k2]
+    if bot1 > 0:
+        fz[..., mo - bot1:, :k2] = f[..., m - bot1:, :k2]
+    return torch.fft.irfft2(fz, s=(mo, no)) * (mo / m) * (no / n)
+
+
+# --------------------------------------------------------------------------
 # 1-D autoregressive rollout core  (utils/autoregressive_step.py:284-309)
 # --------------------------------------------------------------------------
 def rollout_1d(step_fn, state: Tensor, steps: int, mean: float, std: float) -> Tensor:

@@ -66,15 +66,15 @@ __global__ void k_real_synthesis(float* fs, int n, int modes, int kp, double si,
   fs[(long)y * 2 * kp + cim] = im;
 }
 
-// complex forward DFT along an axis of length m restricted to R = 2*m1 row
-// slots (slot r < m1 -> bin r, else bin m - 2*m1 + r) as a real [2R, 2m] block
+// complex forward DFT along an axis of length m restricted to R = top + bot row
+// slots (slot r < top -> bin r, else bin m - bot + (r - top)) as a real [2R, 2m] block
 // matrix; rows 2r+ri2, cols 2*mm+ri1.
-__global__ void k_cplx_analysis(float* t, int m, int m1, double sf) {
-  const int R = 2 * m1;
+__global__ void k_cplx_analysis(float* t, int m, int top, int bot, double sf) {
+  const int R = top + bot;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * m) return;
   const int r = idx / m, mm = idx % m;
-  const int bin = r < m1 ? r : m - 2 * m1 + r;
+  const int bin = r < top ? r : m - bot + (r - top);
   double c, s;
   unit(bin, mm, m, c, s);
   const long ld = 2L * m;
@@ -87,15 +87,15 @@ __global__ void k_cplx_analysis(float* t, int m, int m1, double sf) {
 // inverse: [2m, 2R]; slots r < m1 whose bin is also covered by the upper block
 // (2*m1 > m: the reference's second slice-assign overwrites them, quirk Q6)
 // get zero columns.
-__global__ void k_cplx_synthesis(float* t, int m, int m1, double si) {
-  const int R = 2 * m1;
+__global__ void k_cplx_synthesis(float* t, int m, int top, int bot, double si) {
+  const int R = top + bot;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * m) return;
   const int mm = idx / R, r = idx % R;
-  const int bin = r < m1 ? r : m - 2 * m1 + r;
+  const int bin = r < top ? r : m - bot + (r - top);
   double c, s;
   unit(bin, mm, m, c, s);
-  const bool dead = (r < m1) && (bin >= m - m1);
+  const bool dead = (r < top) && (bin >= m - bot);
   const double a = dead ? 0.0 : si;
   const long ld = 2L * R;
   t[(2L * mm) * ld + 2 * r] = (float)(a * c);
@@ -110,8 +110,8 @@ static void norm_scales(int n, int norm, double& sf, double& si) {
   else { sf = 1.0; si = 1.0 / n; }
 }
 
-static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, int kind, hipStream_t st) {
-  RPDE_CHECK_ARG(n >= 1 && modes >= 1, "plan: bad n=%d modes=%d", n, modes);
+static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, int kind, hipStream_t st, int bot = -1) {
+  RPDE_CHECK_ARG(n >= 1 && modes >= (kind == PLAN_REAL ? 1 : 0), "plan: bad n=%d modes=%d", n, modes);
   RPDE_CHECK_ARG(norm >= 0 && norm <= 2, "plan: bad norm %d", norm);
   rpde_plan* p = new rpde_plan();
   memset(p, 0, sizeof(*p));
@@ -129,14 +129,15 @@ static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, i
     hipLaunchKernelGGL(k_real_analysis, dim3((t1 + 255) / 256), dim3(256), 0, st, p->fa, n, modes, p->kp, p->ldn, sf, planar);
     hipLaunchKernelGGL(k_real_synthesis, dim3((t2 + 255) / 256), dim3(256), 0, st, p->fs, n, modes, p->kp, si, planar);
   } else {
-    RPDE_CHECK_ARG(modes <= n, "plan: m1 %d exceeds M %d", modes, n);
-    const int R = 2 * modes;
+    if (bot < 0) bot = modes;
+    RPDE_CHECK_ARG(modes <= n && bot <= n && modes >= 0 && bot >= 0 && modes + bot >= 1, "plan: rows (%d,%d) vs M %d", modes, bot, n);
+    const int R = modes + bot;
     p->kp = R; p->ldn = 2 * n;
     RPDE_HIP(hipMalloc(&p->fa, sizeof(float) * 2 * R * 2 * n));
     RPDE_HIP(hipMalloc(&p->fs, sizeof(float) * 2 * n * 2 * R));
     const int t = R * n;
-    hipLaunchKernelGGL(k_cplx_analysis, dim3((t + 255) / 256), dim3(256), 0, st, p->fa, n, modes, sf);
-    hipLaunchKernelGGL(k_cplx_synthesis, dim3((t + 255) / 256), dim3(256), 0, st, p->fs, n, modes, si);
+    hipLaunchKernelGGL(k_cplx_analysis, dim3((t + 255) / 256), dim3(256), 0, st, p->fa, n, modes, bot, sf);
+    hipLaunchKernelGGL(k_cplx_synthesis, dim3((t + 255) / 256), dim3(256), 0, st, p->fs, n, modes, bot, si);
   }
   RPDE_LAUNCH_CHECK();
   *out = p;
@@ -145,12 +146,12 @@ static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, i
 
 // ---- cache ------------------------------------------------------------------
 static std::mutex g_mu;
-static std::map<std::tuple<int, int, int, int, int, int>, rpde_plan*> g_cache;
+static std::map<std::tuple<int, int, int, int, int, int, int>, rpde_plan*> g_cache;
 
-int get_plan(const rpde_plan** out, int n, int modes, int norm, int planar, int kind, hipStream_t st) {
+int get_plan(const rpde_plan** out, int n, int modes, int norm, int planar, int kind, hipStream_t st, int bot) {
   int dev = 0;
   RPDE_HIP(hipGetDevice(&dev));
-  const auto key = std::make_tuple(dev, n, modes, norm, planar, kind);
+  const auto key = std::make_tuple(dev, n, modes, norm, planar, kind, bot);
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_cache.find(key);
   if (it != g_cache.end()) { *out = it->second; return RPDE_OK; }
@@ -158,7 +159,7 @@ int get_plan(const rpde_plan** out, int n, int modes, int norm, int planar, int 
   // the first user; later users on other streams of this device are ordered by
   // this one-time synchronisation.
   rpde_plan* p = nullptr;
-  RPDE_TRY(build_plan(&p, n, modes, norm, planar, kind, st));
+  RPDE_TRY(build_plan(&p, n, modes, norm, planar, kind, st, bot));
   RPDE_HIP(hipStreamSynchronize(st));
   g_cache[key] = p;
   *out = p;

@@ -7,7 +7,7 @@ struct rpde_plan {
   int n, modes, norm;
   int planar;   // real plans: 0 rows/cols ordered 2k+ri, 1 ordered ri*kp+k
   int kind;     // PLAN_REAL or PLAN_CPLX
-  int kp;       // real: modes rounded up to 4;  complex: R = 2*m1 row slots
+  int kp;       // real: modes rounded up to 4;  complex: R = top + bot row slots
   int ldn;      // leading dim of fa: real: n rounded up to 4;  complex: 2n
   float* fa;    // real: [2kp, ldn] analysis;     complex: [2R, 2n]
   float* fs;    // real: [n, 2kp] synthesis;      complex: [2n, 2R]
@@ -16,5 +16,6 @@ struct rpde_plan {
 namespace rpde {
 enum { PLAN_REAL = 0, PLAN_CPLX = 1 };
 // cached per (device, n, modes, norm, planar, kind); never freed
-int get_plan(const rpde_plan** out, int n, int modes, int norm, int planar, int kind, hipStream_t st);
+// PLAN_CPLX: `modes` = rows kept from the top of the spectrum, `bot` = rows kept from the bottom (-1: same)
+int get_plan(const rpde_plan** out, int n, int modes, int norm, int planar, int kind, hipStream_t st, int bot = -1);
 }  // namespace rpde

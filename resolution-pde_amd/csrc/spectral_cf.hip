@@ -120,8 +120,10 @@ static int cf_analysis(const rpde_plan* pl, const float* x, float* spec, long ro
   return launch_gemm(d, st);
 }
 // rows x 2kp -> rows x n  (C2R synthesis)
-static int cf_synthesis(const rpde_plan* pl, const float* spec, float* out, long rows, int n, hipStream_t st) {
+static int cf_synthesis(const rpde_plan* pl, const float* spec, float* out, long rows, int n, hipStream_t st,
+                        float alpha = 1.f) {
   rpde_gemm_desc d = gemm_desc();
+  d.alpha = alpha;
   d.A = spec; d.a_kmajor = 1; d.lda = 2L * pl->kp;
   d.B = pl->fs; d.b_kmajor = 1; d.ldb = 2L * pl->kp;
   d.C = out; d.ldc = n;
@@ -288,6 +290,66 @@ int rpde_spectral2d_bwd(const float* grad_out, const float* spec_in, const float
     RPDE_TRY(cf_analysis_T(pn, ds1, grad_x, (long)B * Cin * M, N, act_in, x, st));
   }
   return RPDE_OK;
+}
+
+
+// ---- spectral resize (reference: utils/res_utils.py:29-50 `resize`, :93-125 `resize_1d`) ------------------
+// rfft -> keep the bins both sizes share -> irfft at the new size, times out/in: the same truncated-DFT
+// plans, analysis at the source size and synthesis at the target size.
+size_t rpde_resize1d_ws_bytes(int64_t rows, int n_in, int n_out) {
+  const int k = (n_in / 2 + 1) < (n_out / 2 + 1) ? (n_in / 2 + 1) : (n_out / 2 + 1);
+  return arena_bytes((size_t)rows * 2 * r4(k));
+}
+
+int rpde_resize1d(const float* x, float* out, int64_t rows, int n_in, int n_out, void* ws, size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(x && out && rows > 0 && n_in > 0 && n_out > 0 && rows < (1L << 31), "resize1d: bad arguments");
+  hipStream_t st = as_stream(stream);
+  const int k = (n_in / 2 + 1) < (n_out / 2 + 1) ? (n_in / 2 + 1) : (n_out / 2 + 1);
+  const rpde_plan *pa, *ps;
+  RPDE_TRY(get_plan(&pa, n_in, k, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));
+  RPDE_TRY(get_plan(&ps, n_out, k, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));
+  Arena ar(ws, ws_bytes);
+  float* spec = ar.take((size_t)rows * 2 * pa->kp);
+  if (!ar.ok()) { set_error("resize1d: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  RPDE_TRY(cf_analysis(pa, x, spec, rows, n_in, 0, st));
+  return cf_synthesis(ps, spec, out, rows, n_out, st, (float)((double)n_out / (double)n_in));
+}
+
+size_t rpde_resize2d_ws_bytes(int64_t rows, int M, int N, int Mo, int No) {
+  const int k2 = (N / 2 + 1) < (No / 2 + 1) ? (N / 2 + 1) : (No / 2 + 1);
+  const int top = ((M + 1) / 2) < ((Mo + 1) / 2) ? (M + 1) / 2 : (Mo + 1) / 2;
+  const int bot = (M / 2) < (Mo / 2) ? M / 2 : Mo / 2;
+  const int mm = M > Mo ? M : Mo;
+  return 2 * arena_bytes((size_t)rows * mm * 2 * r4(k2)) + arena_bytes((size_t)rows * 2 * (top + bot) * r4(k2));
+}
+
+// x [rows, M, N] -> out [rows, Mo, No]  (rows = batch * channels)
+int rpde_resize2d(const float* x, float* out, int64_t rows, int M, int N, int Mo, int No, void* ws, size_t ws_bytes,
+                  void* stream) {
+  RPDE_CHECK_ARG(x && out && rows > 0 && M > 0 && N > 0 && Mo > 0 && No > 0 && rows * (long)(M > Mo ? M : Mo) < (1L << 31),
+                 "resize2d: bad arguments");
+  hipStream_t st = as_stream(stream);
+  const int k2 = (N / 2 + 1) < (No / 2 + 1) ? (N / 2 + 1) : (No / 2 + 1);
+  const int top = ((M + 1) / 2) < ((Mo + 1) / 2) ? (M + 1) / 2 : (Mo + 1) / 2;
+  const int bot = (M / 2) < (Mo / 2) ? M / 2 : Mo / 2;
+  const int R = top + bot;
+  const rpde_plan *pn, *pno, *pm, *pmo;
+  RPDE_TRY(get_plan(&pn, N, k2, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));
+  RPDE_TRY(get_plan(&pno, No, k2, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));
+  RPDE_TRY(get_plan(&pm, M, top, RPDE_NORM_BACKWARD, 0, PLAN_CPLX, st, bot));
+  RPDE_TRY(get_plan(&pmo, Mo, top, RPDE_NORM_BACKWARD, 0, PLAN_CPLX, st, bot));
+  const int kp = pn->kp;
+  const int mm = M > Mo ? M : Mo;
+  Arena ar(ws, ws_bytes);
+  float* s1 = ar.take((size_t)rows * mm * 2 * kp);
+  float* t1 = ar.take((size_t)rows * mm * 2 * kp);
+  float* s2 = ar.take((size_t)rows * 2 * R * kp);
+  if (!ar.ok()) { set_error("resize2d: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  RPDE_TRY(cf_analysis(pn, x, s1, rows * M, N, 0, st));
+  RPDE_TRY(cf_rowdft(pm->fa, 2L * M, false, 2 * R, 2 * M, s1, s2, (int)rows, kp, st));
+  RPDE_TRY(cf_rowdft(pmo->fs, 2L * R, false, 2 * Mo, 2 * R, s2, t1, (int)rows, kp, st));
+  const double scale = ((double)Mo / M) * ((double)No / N);
+  return cf_synthesis(pno, t1, out, rows * Mo, No, st, (float)scale);
 }
 
 }  // extern "C"

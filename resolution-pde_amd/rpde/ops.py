@@ -514,3 +514,33 @@ class _RelL2(torch.autograd.Function):
 
 def relative_l2(x, y, size_average: bool = True, reduction: bool = True):
     return _RelL2.apply(x, y, bool(size_average), bool(reduction))
+
+
+# ----------------------------------------------------------------------------
+# spectral resize (evaluation-time data path; no autograd)
+# ----------------------------------------------------------------------------
+def resize1d(x: torch.Tensor, out_size: int) -> torch.Tensor:
+    """x [..., n] -> [..., out_size]: rfft, keep the shared bins, irfft(out_size), times out/in"""
+    lib = load()
+    x = _f32c(x.detach())
+    n = x.shape[-1]
+    rows = x.numel() // n
+    out = torch.empty(*x.shape[:-1], int(out_size), dtype=torch.float32, device=x.device)
+    nws = lib.rpde_resize1d_ws_bytes(rows, n, int(out_size))
+    ws = workspace(nws, x.device)
+    check(lib.rpde_resize1d(ptr(x), ptr(out), rows, n, int(out_size), ws.data_ptr(), nws, stream_ptr()), "resize1d")
+    return out
+
+
+def resize2d(x: torch.Tensor, out_size) -> torch.Tensor:
+    """x [..., M, N] -> [..., Mo, No] (reference utils/res_utils.py `resize`)"""
+    lib = load()
+    x = _f32c(x.detach())
+    M, N = x.shape[-2], x.shape[-1]
+    Mo, No = int(out_size[0]), int(out_size[1])
+    rows = x.numel() // (M * N)
+    out = torch.empty(*x.shape[:-2], Mo, No, dtype=torch.float32, device=x.device)
+    nws = lib.rpde_resize2d_ws_bytes(rows, M, N, Mo, No)
+    ws = workspace(nws, x.device)
+    check(lib.rpde_resize2d(ptr(x), ptr(out), rows, M, N, Mo, No, ws.data_ptr(), nws, stream_ptr()), "resize2d")
+    return out

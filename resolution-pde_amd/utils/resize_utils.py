@@ -1,0 +1,63 @@
+"""All-resolution evaluation core (reference: utils/naive_utils.py:253-507,
+utils/resize_utils.py:27-46): for every resolution in [min, ..., max] obtain the
+test fields at that resolution (stride subsampling = 'naive_downsample', or the
+spectral ``resize``), normalise, run the model, de-normalise, relative L2.
+Plotting / CSV / wandb of the reference are out of scope; the numbers are
+returned."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from utils.loss import RelativeL2Loss
+from utils.res_utils import resize, resize_1d
+
+
+def get_lower_resolutions(base_resolution: int, min_resolution: int = 32) -> List[int]:
+    """base / 2^k down to ``min_resolution``, ascending, ending with the base (e.g. 256 -> [32,64,128,256])"""
+    out = [base_resolution]
+    res = base_resolution // 2
+    while res >= min_resolution:
+        out.insert(0, res)
+        res //= 2
+    return out
+
+
+def to_resolution(fields: torch.Tensor, target: int, how: str = "naive_downsample") -> torch.Tensor:
+    """fields [B,C,n] or [B,C,M,N] at full resolution -> resolution ``target``"""
+    nd = fields.dim() - 2
+    full = fields.shape[-1]
+    if target == full:
+        return fields
+    if how == "naive_downsample":
+        r = full // target
+        return (fields[..., ::r] if nd == 1 else fields[..., ::r, ::r]).contiguous()
+    if how == "resize":
+        return resize_1d(fields, target) if nd == 1 else resize(fields, (target, target))
+    raise ValueError(f"unknown evaluation_type {how}")
+
+
+@torch.no_grad()
+def evaluate_all_resolutions(model, test_x: torch.Tensor, test_y: torch.Tensor, max_resolution: Optional[int] = None,
+                             min_resolution: int = 32, how: str = "naive_downsample", batch_size: int = 16,
+                             x_encode: Optional[Callable] = None, y_decode: Optional[Callable] = None,
+                             device="cuda") -> Dict[int, float]:
+    """{resolution: mean relative L2 over the test batches}; encode/decode are the x / y normalisers"""
+    model.eval()
+    loss_fn = RelativeL2Loss(size_average=True)
+    full = test_x.shape[-1]
+    results: Dict[int, float] = {}
+    for res in get_lower_resolutions(max_resolution or full, min_resolution):
+        total = torch.zeros((), device=device)
+        nb = 0
+        for i in range(0, test_x.shape[0], batch_size):
+            x = to_resolution(test_x[i:i + batch_size].to(device), res, how)
+            y = to_resolution(test_y[i:i + batch_size].to(device), res, how)
+            pred = model(x_encode(x) if x_encode else x)
+            if y_decode:
+                pred = y_decode(pred)
+            total += loss_fn(pred, y)
+            nb += 1
+        results[res] = float(total / max(nb, 1))
+    return results

@@ -112,6 +112,12 @@ CASES = [
          ctor=dict(in_channels=1, out_channels=1, width=32, n_layers=2, n_modes=12, factor=2, ff_weight_norm=True,
                    n_ff_layers=2, layer_norm=True, dropout=0.0, activation="gelu"),
          x=(3, 64), seed=801, steps=4, mean=0.3, std=1.7),
+    # ---- f2: spectral resize used by the resize-mode evaluators ---------------
+    dict(name="resize1d_down", kind="Resize1d", ctor={}, x=(3, 2, 512), out=128, seed=901),
+    dict(name="resize1d_up_odd", kind="Resize1d", ctor={}, x=(2, 3, 33), out=80, seed=902),
+    dict(name="resize2d_down", kind="Resize2d", ctor={}, x=(2, 2, 256, 256), out=(64, 64), seed=903),
+    dict(name="resize2d_up_rect", kind="Resize2d", ctor={}, x=(2, 1, 24, 36), out=(48, 50), seed=904),
+    dict(name="resize2d_odd_down", kind="Resize2d", ctor={}, x=(1, 2, 45, 33), out=(20, 17), seed=905),
 ]
 
 BY_NAME = {c["name"]: c for c in CASES}

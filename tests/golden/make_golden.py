@@ -37,9 +37,10 @@ def _reference_namespace():
     from models.fno import FNO1d, FNO2d
     from models.ffno import FFNO1D, FFNO2D
     from utils.loss import RelativeL2Loss
+    from utils.res_utils import resize, resize_1d
     sys.path.remove(REF)
     # drop the reference's top-level package names so they cannot shadow ours
-    ns = types.SimpleNamespace(**{k: v for k, v in locals().items() if k[0].isupper()})
+    ns = types.SimpleNamespace(**{k: v for k, v in locals().items() if k[0].isupper() or k.startswith("resize")})
     for name in [m for m in sys.modules if m.split(".")[0] in ("models", "utils")]:
         del sys.modules[name]
     return ns
@@ -75,7 +76,7 @@ def main(argv):
         if want and case["name"] not in want:
             continue
         t0 = time.time()
-        spec = {} if case["kind"] == "RelativeL2Loss" else backend.spec(case)
+        spec = {} if case["kind"] in ("RelativeL2Loss", "Resize1d", "Resize2d") else backend.spec(case)
         sd = synth.fill_state_dict(spec, case["seed"])
         res = run_case(case, backend, sd)
         floors = {}

@@ -41,6 +41,8 @@ class ModuleBackend:
 
     def spec(self, case) -> Dict:
         kind = case.get("model", case["kind"])
+        if kind in ("Resize1d", "Resize2d"):
+            return {}
         if kind == "Rollout1d":
             kind = "FFNO1D"
         return synth.spec_of(getattr(self.ns, kind)(**self.ctor(case)).state_dict())
@@ -52,6 +54,9 @@ class ModuleBackend:
         if kind == "RelativeL2Loss":
             mod = self.ns.RelativeL2Loss(**case["ctor"])
             return Instance({}, None, mod)
+        if kind in ("Resize1d", "Resize2d"):
+            fn = self.ns.resize_1d if kind == "Resize1d" else self.ns.resize
+            return Instance({}, fn, None)
         mod = getattr(self.ns, kind)(**self.ctor(case))
         got = synth.spec_of(mod.state_dict())
         want = synth.spec_of(sd)
@@ -78,6 +83,10 @@ class OracleBackend:
         c = dict(case["ctor"])
         if kind == "RelativeL2Loss":
             return Instance({}, None, lambda a, b: R.relative_l2(a, b, **c))
+        if kind == "Resize1d":
+            return Instance({}, R.resize_1d, None)
+        if kind == "Resize2d":
+            return Instance({}, R.resize_2d, None)
         p = R.make_params(sd)
         if kind == "SpectralConv1d":
             call = lambda x: R.spectral_conv1d(x, p["weights1"])
@@ -188,6 +197,11 @@ def run_case(case, backend, sd: Optional[Mapping[str, torch.Tensor]] = None) -> 
         res["loss"] = loss
         for k, v in inst.leaves.items():
             res["param/" + k] = v
+    elif kind in ("Resize1d", "Resize2d"):
+        x = synth.rand_tensor(case["x"], seed, "x").to(dev)
+        out = case["out"]
+        with torch.no_grad():
+            res["out"] = inst.call(x, tuple(out) if kind == "Resize2d" else out)
     elif kind == "Rollout1d":
         state = synth.smooth_field((case["x"][0], 1, case["x"][1]), seed, "x")[:, 0].to(dev)
         mean, std = case["mean"], case["std"]

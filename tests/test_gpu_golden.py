@@ -27,6 +27,7 @@ def _namespace():
     from models.fno import FNO1d, FNO2d
     from models.spectral_convolution import FSpectralConv1d, FSpectralConv2d, SpectralConv1d, SpectralConv2d
     from utils.loss import RelativeL2Loss
+    from utils.res_utils import resize, resize_1d
     return types.SimpleNamespace(**{k: v for k, v in locals().items()})
 
 
