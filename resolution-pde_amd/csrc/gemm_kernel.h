@@ -159,8 +159,9 @@ struct Tile {
 
 // PRO: 0 no staged activation, 1 on A, 2 on B.  BK: k-extent of a stage; STAGES: LDS stages (2 = double
 // buffered, one barrier per stage; 1 = single buffer, two barriers, half the LDS -> more resident waves)
-template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PRO, bool VEC, int BK = 32, int STAGES = 2, bool PIPE = false>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PRO, bool VEC, int BK = 32, int STAGES = 2, bool PIPE = false,
+          bool PREAUX = false>
+__global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(const GemmK g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
   using TA = Tile<BM, BK, AK, VEC, PRO == 1>;
@@ -213,6 +214,27 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // PREAUX (short reductions, HBM/latency bound): fetch the rows the epilogue will need (stored derivative
+  // `aux` for RPDE_EPI_MULAUX, old C for accumulate) now, so they fly during the operand loads and MFMAs
+  constexpr int PA_SMEM = STAGES * (Tile<BM, BK, AK, VEC, false>::LDS_FLOATS + Tile<BN, BK, BKM, VEC, false>::LDS_FLOATS);
+  constexpr int PA_EP = (BM * BN + PA_SMEM - 1) / PA_SMEM;
+  constexpr int PA_SLAB = BM / PA_EP, PA_VPR = BN / 4, PA_RSTEP = NTHREADS / PA_VPR;
+  constexpr int PA_NV4 = PA_SLAB * BN / 4 / NTHREADS;
+  float4 pre[PREAUX ? PA_EP * PA_NV4 : 1];
+  if constexpr (PREAUX) {
+    const float* __restrict__ src = g.accumulate ? C : g.aux + coff;
+    const long lds_ = g.accumulate ? g.ldc : g.ldaux;
+    const int c4p = (tid % PA_VPR) * 4, row0p = tid / PA_VPR;
+    const int gnp = min(n0 + c4p, g.N - 4);
+#pragma unroll
+    for (int e = 0; e < PA_EP; ++e)
+#pragma unroll
+      for (int it = 0; it < PA_NV4; ++it) {
+        const int gm = min(m0 + e * PA_SLAB + row0p + it * PA_RSTEP, g.M - 1);
+        pre[e * PA_NV4 + it] = *reinterpret_cast<const float4*>(src + (long)gm * lds_ + gnp);
+      }
+  }
 
   const bool drop_a = g.drop.on() && (g.drop_where & 1);
   const bool drop_b = g.drop.on() && (g.drop_where & 2);
@@ -357,7 +379,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
       }
       __syncthreads();
       if (gn < g.N) {
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < NV4; ++it) {
           const int row = row0 + it * RSTEP;
           const int gm = m0 + e * SLAB + row;
@@ -367,7 +389,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
           v.z = fmaf(v.z, g.alpha, bn4.z); v.w = fmaf(v.w, g.alpha, bn4.w);
           if (g.bias_mode == 2) { const float bm = g.bias[gm]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
           if (g.epi_dact == RPDE_EPI_MULAUX) {
-            const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
+            float4 a;
+            if constexpr (PREAUX) a = pre[e * NV4 + it];
+            else a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
             v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
           } else if (g.epi_dact) {
             float s[4] = {1.f, 1.f, 1.f, 1.f};
@@ -379,7 +403,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
             v.w *= dact_f(g.epi_dact, a.w * s[3]) * s[3];
           }
           float4* cp = reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn);
-          if (g.accumulate) { const float4 o = *cp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          if (g.accumulate) {
+            float4 o;
+            if constexpr (PREAUX) o = pre[e * NV4 + it];
+            else o = *cp;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
           if (g.write_act) {
             float s[4] = {1.f, 1.f, 1.f, 1.f};
             if (drop_e && !g.epi_dact) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
@@ -457,17 +486,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmK g) {
 // ---- host-side dispatch, instantiated once per operand layout (one translation
 // unit each, so the instantiations compile in parallel).  PM: bit p set <=> the
 // staged-activation variant PRO = p is built for this layout.
-template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PM, bool VEC, int BK = 32, int STAGES = 2, bool PIPE = false>
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PM, bool VEC, int BK = 32, int STAGES = 2, bool PIPE = false,
+          bool PREAUX = false>
 inline void launch_pro(const GemmK& g, int pro, dim3 grid, hipStream_t st) {
   if (pro == 0) {
     if constexpr ((PM & 1) != 0)
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 0, VEC, BK, STAGES, PIPE>), grid, dim3(NTHREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 0, VEC, BK, STAGES, PIPE, PREAUX>), grid, dim3(NTHREADS), 0, st, g);
   } else if (pro == 1) {
     if constexpr ((PM & 2) != 0)
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 1, VEC, BK, STAGES, PIPE>), grid, dim3(NTHREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 1, VEC, BK, STAGES, PIPE, PREAUX>), grid, dim3(NTHREADS), 0, st, g);
   } else {
     if constexpr ((PM & 4) != 0)
-      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 2, VEC, BK, STAGES, PIPE>), grid, dim3(NTHREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, AK, BKM, 2, VEC, BK, STAGES, PIPE, PREAUX>), grid, dim3(NTHREADS), 0, st, g);
   }
 }
 
@@ -481,15 +511,22 @@ inline int launch_layout_impl(const GemmK& g, int bm, int bn, int pro, bool vec,
   }
   // RPDE_GEMM_VARIANT (A/B experiments, same-box numbers in profiles/r01_c_gemm_variants.txt):
   //   0 default: two-deep software pipeline on every vector tile;  1: lean loop on the small tiles;
-  //   2: lean loop everywhere.  (Smaller-LDS variants -- BK16 x 2, BK32 x 1 -- were within 2 %: the
+  //   2: lean loop everywhere;  3: no lean single-stage kernel for short reductions;  4: no epilogue prefetch.  (Smaller-LDS variants -- BK16 x 2, BK32 x 1 -- were within 2 %: the
   //   resident-wave count is not what limits this kernel.)
   const int v = gemm_variant();
-  const bool pipe_big = v != 2, pipe_small = v == 0;
+  const bool pipe_big = v != 2, pipe_small = v != 1 && v != 2;
   if (!vec) launch_pro<2, 2, 1, 1, AK, BKM, PM, false>(g, pro, grid, st);            // 64 x 64, scalar loads
   else if (bm == 128 && bn == 128) {
     // reductions of <= 2 stages are epilogue / HBM-latency bound: lean single-stage kernel (~90 VGPRs,
     // 37 KB LDS -> 4 workgroups per CU) keeps more memory requests in flight  (variant 3 disables)
-    if (g.kchunk <= 64 && v != 3 && v != 2) launch_pro<2, 2, 2, 2, AK, BKM, PM, true, 32, 1, false>(g, pro, grid, st);
+    const bool preaux = g.cvec && pro == 0 && v != 4 && !g.write_act &&
+                        ((g.epi_dact == RPDE_EPI_MULAUX) != (g.accumulate != 0));   // exactly one of the two
+    if (g.kchunk <= 64 && v != 3 && v != 2) {
+      if constexpr ((PM & 1) != 0) {
+        if (preaux) launch_pro<2, 2, 2, 2, AK, BKM, 1, true, 32, 1, false, true>(g, pro, grid, st);
+        else launch_pro<2, 2, 2, 2, AK, BKM, PM, true, 32, 1, false>(g, pro, grid, st);
+      }
+    }
     else if (pipe_big) launch_pro<2, 2, 2, 2, AK, BKM, PM, true, 32, 2, true>(g, pro, grid, st);
     else launch_pro<2, 2, 2, 2, AK, BKM, PM, true>(g, pro, grid, st);
   } else if (bm == 128 && bn == 64) {
