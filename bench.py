@@ -7,9 +7,10 @@ synthetic fields (BASELINE.json configs[2]), one process per GPU.
 A step = forward + relative-L2 loss + backward + gradient all-reduce (N>1) +
 AdamW on one batch of B samples per GPU, inputs resident in HBM.  Rank 0 prints
 ONE JSON line.  It also carries
-  * roofline: the dominant kernel (the 256->256 FeedForward GEMM with its fused
-    GELU+dropout staging) timed live with HIP events on the launch stream,
-    achieved fp32-MFMA TFLOP/s against the 157.3 TF peak;
+  * roofline: the dominant kernel (the 256->256 FeedForward GEMM whose epilogue
+    stores gelu(dropout(z)) and its derivative) timed live with HIP events on
+    the launch stream, achieved fp32-MFMA TFLOP/s against the 157.3 TF peak;
+    roofline_extra: the layer's backward-data and weight-gradient GEMMs;
   * roofline_spectral: the FSpectralConv2d.forward_fourier pipeline, algorithmic
     bytes (SURVEY 8d: 33.55 MB*B + 1.31 MB per layer forward) against 8 TB/s;
   * cpu_baseline: the CPU oracle's training step timed on the host cores
@@ -56,33 +57,69 @@ def synth_batch(b, res, seed, device):
     return out
 
 
-def time_ff_gemm(B, device, iters=20):
-    """dominant kernel: z2 = gelu(dropout(z1)) @ W2^T + b2, [P,256]x[256,256], P = B*65536"""
+def _time_gemm(desc, iters):
     from rpde import _lib
     lib = _lib.load()
-    P, K, N = B * RES * RES, 256, 256
-    z1 = torch.randn(P, K, device=device)
-    w = torch.randn(N, K, device=device) * 0.06
-    b = torch.randn(N, device=device)
-    out = torch.empty(P, N, device=device)
-    d = _lib.GemmDesc()
-    d.A, d.B, d.C = z1.data_ptr(), w.data_ptr(), out.data_ptr()
-    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = P, N, K, 1, 1
-    d.lda, d.ldb, d.ldc, d.batch, d.zdiv, d.ksplit, d.alpha = K, K, N, 1, 1, 1, 1.0
-    d.bias, d.bias_mode, d.act_a = b.data_ptr(), 1, 1
-    d.drop_p, d.drop_seed, d.drop_ld, d.drop_where = 0.1, 12345, K, 1
     st = _lib.stream_ptr()
     for _ in range(3):
-        _lib.check(lib.rpde_gemm_f32(C.byref(d), st), "gemm")
+        _lib.check(lib.rpde_gemm_f32(C.byref(desc), st), "gemm")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        _lib.check(lib.rpde_gemm_f32(C.byref(d), st), "gemm")
+        _lib.check(lib.rpde_gemm_f32(C.byref(desc), st), "gemm")
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    return e0.elapsed_time(e1) / iters
+
+
+def time_ff_gemm(B, device, iters=20):
+    """dominant kernel of the training step: FeedForward layer-2 forward,
+    z2 = h1 @ W2^T + b2 with the epilogue that stores h2 = gelu(dropout(z2)) and d2 = gelu'(.)*scale,
+    [P,256]x[256,256], P = B*65536.  Also times the two other heavy kernels of the layer (backward-data
+    through the stored derivative, weight gradient split over the points) for roofline_extra."""
+    from rpde import _lib
+    P, K, N = B * RES * RES, 256, 256
+    h1 = torch.randn(P, K, device=device)
+    w = torch.randn(N, K, device=device) * 0.06
+    b = torch.randn(N, device=device)
+    h2 = torch.empty(P, N, device=device)
+    d2 = torch.empty(P, N, device=device)
     flops = 2.0 * P * K * N
-    return ms, flops / (ms * 1e-3) / 1e12, flops
+
+    def base():
+        d = _lib.GemmDesc()
+        d.batch, d.zdiv, d.ksplit, d.alpha = 1, 1, 1, 1.0
+        return d
+
+    d = base()                                           # forward
+    d.A, d.B, d.C = h1.data_ptr(), w.data_ptr(), h2.data_ptr()
+    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = P, N, K, 1, 1
+    d.lda, d.ldb, d.ldc = K, K, N
+    d.bias, d.bias_mode, d.write_act, d.aux_out = b.data_ptr(), 1, 1, d2.data_ptr()
+    d.drop_p, d.drop_seed, d.drop_ld, d.drop_where = 0.1, 12345, N, 4
+    ms = _time_gemm(d, iters)
+    extra = []
+    e = base()                                           # backward-data: gx = (g @ W) * d + per-tile column sums
+    cs = torch.empty(((P + 127) // 128) * K, device=device)
+    e.A, e.B, e.C = h2.data_ptr(), w.data_ptr(), h1.data_ptr()
+    e.M, e.N, e.K, e.a_kmajor, e.b_kmajor = P, K, N, 1, 0
+    e.lda, e.ldb, e.ldc = N, K, K
+    e.epi_dact, e.aux, e.ldaux, e.colsum = 100, d2.data_ptr(), K, cs.data_ptr()
+    t = _time_gemm(e, max(5, iters // 2))
+    extra.append({"kernel": "gemm_f32 NN backward-data [P,256]x[256,256] * stored derivative + bias column sums",
+                  "bound": "mfma", "achieved": round(flops / (t * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TF,
+                  "unit": "TFLOP/s", "frac": round(flops / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4), "ms_per_launch": round(t, 4)})
+    f = base()                                           # weight gradient: W' = g^T @ h, split over the points
+    S = 128
+    slabs = torch.empty(S * N * K, device=device)
+    f.A, f.B, f.C = h2.data_ptr(), h1.data_ptr(), slabs.data_ptr()
+    f.M, f.N, f.K, f.a_kmajor, f.b_kmajor = N, K, P, 0, 0
+    f.lda, f.ldb, f.ldc, f.ksplit, f.sCk = N, K, K, S, N * K
+    t = _time_gemm(f, max(5, iters // 2))
+    extra.append({"kernel": "gemm_f32 TN weight gradient [256,P]x[P,256], split-K 128 slabs", "bound": "mfma",
+                  "achieved": round(flops / (t * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                  "frac": round(flops / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4), "ms_per_launch": round(t, 4)})
+    return ms, flops / (ms * 1e-3) / 1e12, flops, extra
 
 
 def time_spectral(B, device, iters=10):
@@ -234,7 +271,7 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        g_ms, g_tf, g_flops = time_ff_gemm(B, device)
+        g_ms, g_tf, g_flops, g_extra = time_ff_gemm(B, device)
         log(f"FF GEMM {g_ms:.3f} ms = {g_tf:.1f} TF")
         s_ms, s_gbs, s_bytes = time_spectral(B, device)
         log(f"spectral fwd {s_ms:.3f} ms = {s_gbs:.0f} GB/s algorithmic")
@@ -255,10 +292,11 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "grid": [RES, RES], "optimizer": "AdamW lr=1e-3",
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_bucket_bytes": bucket.nbytes,
                        "mean_train_rel_l2": round(mean_loss, 6)},
-            "roofline": {"kernel": "gemm_f32 NT [P,256]x[256,256]+bias, GELU+dropout staged (FeedForward layer 2 fwd)",
+            "roofline": {"kernel": "gemm_f32 NT [P,256]x[256,256]+bias -> h=gelu(dropout(z)), d=gelu'*scale (FeedForward layer 2 fwd)",
                          "bound": "mfma", "achieved": round(g_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                          "frac": round(g_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
                          "flops_per_launch": g_flops, "ms_per_launch": round(g_ms, 4)},
+            "roofline_extra": g_extra,
             "roofline_spectral": {"kernel": "FSpectralConv2d.forward_fourier (6 GEMM launches + weight pack)",
                                   "bound": "hbm", "achieved": round(s_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": round(s_gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": s_bytes,
