@@ -415,12 +415,14 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
             v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
             if (g.aux_out) {
               float4 dv;
-              dv.x = dact_f(g.write_act, v.x) * s[0]; dv.y = dact_f(g.write_act, v.y) * s[1];
-              dv.z = dact_f(g.write_act, v.z) * s[2]; dv.w = dact_f(g.write_act, v.w) * s[3];
+              act_both(g.write_act, v.x, v.x, dv.x); act_both(g.write_act, v.y, v.y, dv.y);
+              act_both(g.write_act, v.z, v.z, dv.z); act_both(g.write_act, v.w, v.w, dv.w);
+              dv.x *= s[0]; dv.y *= s[1]; dv.z *= s[2]; dv.w *= s[3];
               *reinterpret_cast<float4*>(g.aux_out + coff + (long)gm * g.ldc + gn) = dv;
+            } else {
+              v.x = act_f(g.write_act, v.x); v.y = act_f(g.write_act, v.y);
+              v.z = act_f(g.write_act, v.z); v.w = act_f(g.write_act, v.w);
             }
-            v.x = act_f(g.write_act, v.x); v.y = act_f(g.write_act, v.y);
-            v.z = act_f(g.write_act, v.z); v.w = act_f(g.write_act, v.w);
           }
           *cp = v;
           csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;

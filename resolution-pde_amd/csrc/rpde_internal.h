@@ -43,42 +43,49 @@ void set_error(const char* fmt, ...);
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- device math -----------------------------------------------------------
-// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) in ~20 VALU instructions instead of the
-// device library's erff (the GELU staged into the GEMM operands must not cost
-// more issue slots than the 64-cycle fp32 MFMAs it hides behind).
-//   |u| <  1 : erf(u)  = u * P1(u^2)            (degree-5 fit, own Chebyshev fit)
-//   |u| >= 1 : erfc(t) = exp(P2(t)), t = |u|    (degree-7 fit of log erfc on [1,4])
-// max |erf error| 1.3e-7 (~1 ulp at 1) against scipy.special.erf over [-6,6];
-// the erfc form keeps full relative accuracy in the negative tail where
-// 0.5 x (1 + erf) cancels.
+// Phi(x) = 0.5 erfc(-x / sqrt 2) and the Gaussian factor exp(-x^2/2) from ONE exponential
+// (Abramowitz & Stegun 7.1.26):  erfc(t) = (a1 s + ... + a5 s^5) exp(-t^2),  s = 1 / (1 + p t),  t = |x| / sqrt 2.
+// About 14 VALU instructions for Phi, 4 more for GELU and GELU' together, instead of the device
+// library's erff (~100): on gfx950 the fp32 MFMA shares the fp32 lanes with the VALU, so epilogue math
+// is paid in matrix throughput.  Measured in fp32 against scipy over [-9, 9]: |Phi error| <= 3.0e-7,
+// |gelu error| <= 4.2e-7, |gelu' error| <= 3.2e-7 (parity budget of the hot path: 1e-5).
+__device__ __forceinline__ void phi_parts(float x, float& cdf, float& gauss) {
+  const float t = fabsf(x) * 0.70710678118654752440f;
+  const float s = __builtin_amdgcn_rcpf(fmaf(0.3275911f, t, 1.0f));
+  gauss = __expf(-t * t);                                   // = exp(-x^2 / 2)
+  float p = 1.061405429f;
+  p = fmaf(p, s, -1.453152027f);
+  p = fmaf(p, s, 1.421413741f);
+  p = fmaf(p, s, -0.284496736f);
+  p = fmaf(p, s, 0.254829592f);
+  const float half = 0.5f * p * s * gauss;                  // 0.5 erfc(t)
+  cdf = x < 0.f ? half : 1.0f - half;
+}
 __device__ __forceinline__ float norm_cdf_f(float x) {
-  const float u = x * 0.70710678118654752440f;
-  const float t = fabsf(u);
-  const float s = u * u;
-  float p = -5.654105917e-04f;
-  p = fmaf(p, s, 4.923277535e-03f);
-  p = fmaf(p, s, -2.671638504e-02f);
-  p = fmaf(p, s, 1.128036454e-01f);
-  p = fmaf(p, s, -3.761234879e-01f);
-  p = fmaf(p, s, 1.128379107e+00f);
-  const float small = fmaf(0.5f * u, p, 0.5f);
-  const float tc = fminf(t, 4.0f);
-  float q = -1.330938994e-05f;
-  q = fmaf(q, tc, 3.175720340e-04f);
-  q = fmaf(q, tc, -3.436867613e-03f);
-  q = fmaf(q, tc, 2.262198552e-02f);
-  q = fmaf(q, tc, -1.033189818e-01f);
-  q = fmaf(q, tc, -6.390933394e-01f);
-  q = fmaf(q, tc, -1.125925899e+00f);
-  q = fmaf(q, tc, -7.569686277e-04f);
-  const float half_e = t > 4.0f ? 0.f : 0.5f * __expf(q);
-  const float big = u < 0.f ? half_e : 1.0f - half_e;
-  return t < 1.0f ? small : big;
+  float c, g;
+  phi_parts(x, c, g);
+  return c;
 }
 __device__ __forceinline__ float gelu_f(float u) { return u * norm_cdf_f(u); }
 __device__ __forceinline__ float dgelu_f(float u) {
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
-  return fmaf(u, pdf, norm_cdf_f(u));
+  float c, g;
+  phi_parts(u, c, g);
+  return fmaf(u * g, 0.39894228040143267794f, c);
+}
+// h = act(u), d = act'(u) in one evaluation
+__device__ __forceinline__ void act_both(int act, float u, float& h, float& d) {
+  if (act == RPDE_ACT_GELU) {
+    float c, g;
+    phi_parts(u, c, g);
+    h = u * c;
+    d = fmaf(u * g, 0.39894228040143267794f, c);
+  } else if (act == RPDE_ACT_RELU) {
+    h = u > 0.f ? u : 0.f;
+    d = u > 0.f ? 1.f : 0.f;
+  } else {
+    h = u;
+    d = 1.f;
+  }
 }
 __device__ __forceinline__ float act_f(int act, float u) {
   if (act == RPDE_ACT_GELU) return gelu_f(u);
