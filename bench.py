@@ -9,7 +9,8 @@ AdamW on one batch of B samples per GPU, inputs resident in HBM.  Rank 0 prints
 ONE JSON line.  It also carries
   * roofline: the dominant kernel (the 256->256 FeedForward GEMM whose epilogue
     stores gelu(dropout(z)) and its derivative) timed live with HIP events on
-    the launch stream, achieved fp32-MFMA TFLOP/s against the 157.3 TF peak;
+    the launch stream: algorithmic bytes per launch / time against 8 TB/s (the
+    split-bf16 kernel makes it HBM bound), fp32-equivalent TFLOP/s beside it;
     roofline_extra: the layer's backward-data and weight-gradient GEMMs;
   * roofline_spectral: the FSpectralConv2d.forward_fourier pipeline, algorithmic
     bytes (SURVEY 8d: 33.55 MB*B + 1.31 MB per layer forward) against 8 TB/s;
@@ -39,6 +40,7 @@ CFG3 = dict(in_channels=1, out_channels=1, width=64, n_layers=4, n_modes=20, fac
 RES = 256
 PEAK_F32_MFMA_TF = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0         # HBM3E spec; 6290 measured-achievable
+PEAK_BF16_MFMA_TF = 2500.0    # dense bf16 matrix peak; the split-bf16 fp32 GEMM spends 6 bf16 flops per fp32 flop
 
 
 def synth_batch(b, res, seed, device):
@@ -101,14 +103,17 @@ def time_ff_gemm(B, device, iters=20):
     extra = []
     e = base()                                           # backward-data: gx = (g @ W) * d + per-tile column sums
     cs = torch.empty(((P + 127) // 128) * K, device=device)
-    e.A, e.B, e.C = h2.data_ptr(), w.data_ptr(), h1.data_ptr()
-    e.M, e.N, e.K, e.a_kmajor, e.b_kmajor = P, K, N, 1, 0
-    e.lda, e.ldb, e.ldc = N, K, K
+    wt = w.t().contiguous()                              # training transposes the 256x256 weight once per call
+    e.A, e.B, e.C = h2.data_ptr(), wt.data_ptr(), h1.data_ptr()
+    e.M, e.N, e.K, e.a_kmajor, e.b_kmajor = P, K, N, 1, 1
+    e.lda, e.ldb, e.ldc = N, N, K
     e.epi_dact, e.aux, e.ldaux, e.colsum = 100, d2.data_ptr(), K, cs.data_ptr()
     t = _time_gemm(e, max(5, iters // 2))
-    extra.append({"kernel": "gemm_f32 NN backward-data [P,256]x[256,256] * stored derivative + bias column sums",
-                  "bound": "mfma", "achieved": round(flops / (t * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TF,
-                  "unit": "TFLOP/s", "frac": round(flops / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4), "ms_per_launch": round(t, 4)})
+    byt = 4.0 * P * (N + 2 * K)                          # read g, read d, write gx
+    extra.append({"kernel": "gemm split-bf16 NT backward-data [P,256]x[256,256] * stored derivative + bias column sums",
+                  "bound": "hbm", "achieved": round(byt / (t * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                  "frac": round(byt / (t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "ms_per_launch": round(t, 4),
+                  "fp32_equiv_tflops": round(flops / (t * 1e-3) / 1e12, 2)})
     f = base()                                           # weight gradient: W' = g^T @ h, split over the points
     S = 128
     slabs = torch.empty(S * N * K, device=device)
@@ -119,7 +124,8 @@ def time_ff_gemm(B, device, iters=20):
     extra.append({"kernel": "gemm_f32 TN weight gradient [256,P]x[P,256], split-K 128 slabs", "bound": "mfma",
                   "achieved": round(flops / (t * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
                   "frac": round(flops / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4), "ms_per_launch": round(t, 4)})
-    return ms, flops / (ms * 1e-3) / 1e12, flops, extra
+    alg_bytes = 4.0 * P * (K + 2 * N) + 4.0 * N * K         # read h1, write h2 and d2, read W2
+    return ms, flops / (ms * 1e-3) / 1e12, flops, extra, alg_bytes
 
 
 def time_spectral(B, device, iters=10):
@@ -271,7 +277,7 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        g_ms, g_tf, g_flops, g_extra = time_ff_gemm(B, device)
+        g_ms, g_tf, g_flops, g_extra, g_bytes = time_ff_gemm(B, device)
         log(f"FF GEMM {g_ms:.3f} ms = {g_tf:.1f} TF")
         s_ms, s_gbs, s_bytes = time_spectral(B, device)
         log(f"spectral fwd {s_ms:.3f} ms = {s_gbs:.0f} GB/s algorithmic")
@@ -292,10 +298,16 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "grid": [RES, RES], "optimizer": "AdamW lr=1e-3",
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_bucket_bytes": bucket.nbytes,
                        "mean_train_rel_l2": round(mean_loss, 6)},
-            "roofline": {"kernel": "gemm_f32 NT [P,256]x[256,256]+bias -> h=gelu(dropout(z)), d=gelu'*scale (FeedForward layer 2 fwd)",
-                         "bound": "mfma", "achieved": round(g_tf, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                         "frac": round(g_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
-                         "flops_per_launch": g_flops, "ms_per_launch": round(g_ms, 4)},
+            # fp32 in/out/accumulate; products on the bf16 matrix pipe by exact 3-way splitting (6 MFMA terms):
+            # compute roof 2500/6 = 417 TF(fp32-equivalent), arithmetic intensity 43 flop/B < ridge 52 -> HBM bound
+            "roofline": {"kernel": "gemm split-bf16 NT [P,256]x[256,256]+bias -> h=gelu(dropout(z)), d=gelu'*scale "
+                                   "(FeedForward layer 2 forward)",
+                         "bound": "hbm", "achieved": round(g_bytes / (g_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": g_bytes, "flops_per_launch": g_flops,
+                         "ms_per_launch": round(g_ms, 4), "fp32_equiv_tflops": round(g_tf, 2),
+                         "frac_of_fp32_mfma_peak": round(g_tf / PEAK_F32_MFMA_TF, 4),
+                         "frac_of_split_bf16_compute_roof": round(g_tf / (PEAK_BF16_MFMA_TF / 6), 4)},
             "roofline_extra": g_extra,
             "roofline_spectral": {"kernel": "FSpectralConv2d.forward_fourier (6 GEMM launches + weight pack)",
                                   "bound": "hbm", "achieved": round(s_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -79,11 +79,18 @@ static inline bool can_fuse_colsum(const float* gy, const float* w, const float*
 }
 
 // gx[P,in] = (gy[P,out] . W[out,in]) (* dstored[P,in] when given: the derivative saved by the forward epilogue)
+// wt: optional scratch of in_f*out_f floats: W is transposed into it first so that both operands are
+// k-major and the GEMM can take the split-bf16 path
 static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f,
-                             const float* dstored, float* colsum_slab, hipStream_t st) {
+                             const float* dstored, float* colsum_slab, hipStream_t st, float* wt = nullptr) {
   rpde_gemm_desc d = gemm_desc();
   d.A = gy; d.a_kmajor = 1; d.lda = out_f;
-  d.B = w; d.b_kmajor = 0; d.ldb = in_f;
+  if (wt) {
+    RPDE_TRY(rpde_transpose_cs(w, wt, 1, out_f, in_f, 1, st));     // [out,in] -> [in,out]
+    d.B = wt; d.b_kmajor = 1; d.ldb = out_f;
+  } else {
+    d.B = w; d.b_kmajor = 0; d.ldb = in_f;
+  }
   d.C = gx; d.ldc = in_f;
   d.M = (int)P; d.N = in_f; d.K = out_f;
   if (dstored) { d.epi_dact = RPDE_EPI_MULAUX; d.aux = dstored; d.ldaux = in_f; }
@@ -116,7 +123,7 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
   if (t > small) small = t;
   const size_t c = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
   if (c > small) small = c;
-  return 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small);
+  return 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small) + arena_bytes((size_t)hid * hid);
 }
 
 int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs,
@@ -161,6 +168,7 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   if (ff_tail_bwd_ws_floats(P, p->dim) > small_n) small_n = ff_tail_bwd_ws_floats(P, p->dim);
   if ((size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid > small_n) small_n = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
   float* small = ar.take(small_n);
+  float* wt = ar.take((size_t)hid * hid);
   if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
 
   // tail: d(out) -> dz_{L-1}, d(gamma), d(beta) and, fused, the last layer's bias gradient
@@ -179,7 +187,7 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
     if (l > 0) {
       RPDE_CHECK_ARG(ds[l - 1], "feedforward_bwd: derivative of layer %d was not saved", l - 1);
       const bool fuse = grad_biases && can_fuse_colsum(dz, p->weights[l], other, ds[l - 1], P, in_f, out_f);
-      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, ds[l - 1], fuse ? small : nullptr, st));
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, ds[l - 1], fuse ? small : nullptr, st, wt));
       if (fuse) {
         RPDE_TRY(reduce_slabs_2pass(small, grad_biases[l - 1], in_f, (int)colsum_tiles(P), in_f,
                                     small + colsum_tiles(P) * in_f, st));
@@ -187,7 +195,7 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
       }
       float* t = dz; dz = other; other = t;
     } else if (grad_x) {
-      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, nullptr, nullptr, st));
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, nullptr, nullptr, st, wt));
     }
   }
   return RPDE_OK;

@@ -1,0 +1,339 @@
+// fp32 GEMM on the bf16 matrix pipe by exact-product splitting.
+//
+// On gfx950 v_mfma_f32_32x32x2_f32 runs at the vector fp32 rate and (measured) does
+// not overlap with VALU work: it is the slow path for fp32 matrix products.  The bf16 MFMA pipe is
+// separate and 16x faster per flop.  Every fp32 value is the exact sum of three bf16 values,
+//      a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)      (3 x 8 = 24 mantissa bits),
+// and a bf16 x bf16 product is exact in fp32, so
+//      a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2) + O(2^-24 |ab|)
+// -- six v_mfma_f32_32x32x16_bf16 per fp32 tile product, accumulated in fp32.  Inputs, outputs and
+// accumulation stay fp32; the dropped terms are below the fp32 rounding of the product itself, so the
+// result has fp32-GEMM accuracy (tests: <= 2e-6 rel-L2 against float64, same bound as the fp32-MFMA kernel;
+// every golden-vector parity test runs through this kernel).  Effective rate: 16/6 = 2.7x the fp32 MFMA
+// peak, which turns the FeedForward GEMMs from ALU bound into HBM bound.
+//
+// Structure: 256 threads = 4 waves (WM x WN) x (TM x TN) tiles of 32x32, BK = 32 per stage, one LDS stage
+// + register prefetch (two barriers per stage, 48 KB LDS -> 3 workgroups per CU).  The splitting happens
+// while a tile moves registers -> LDS; LDS holds three bf16 images per operand as [row][32 k] = 64-byte
+// rows whose 16-byte chunks are XOR-swizzled with (row>>2)&3, so the ds_read_b128 fragment reads
+// (lane = row, 8 consecutive k) are bank-conflict free without padding.  x-major operands (reduction
+// index slow in memory: weight gradients, backward-data weights) are transposed on the way into LDS:
+// each thread loads the same 4 rows at two adjacent k and writes packed (k, k+1) bf16 pairs.
+// The epilogue is the fp32 kernel's (LDS-staged 16-byte rows, bias / activation+derivative / multiply by
+// stored derivative / accumulate / per-tile column sums).
+#include "gemm_kernel.h"
+
+namespace rpde {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XBK = 32;
+
+// three bf16 pieces of two floats, packed pairwise (low half = first element)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  union { bf16x2 v; unsigned u; } ph, pm, pl;
+  f32x2 x = {x0, x1};
+  ph.v = __builtin_convertvector(x, bf16x2);
+  f32x2 r1 = x - __builtin_convertvector(ph.v, f32x2);
+  pm.v = __builtin_convertvector(r1, bf16x2);
+  f32x2 r2 = r1 - __builtin_convertvector(pm.v, f32x2);
+  pl.v = __builtin_convertvector(r2, bf16x2);
+  h = ph.u; m = pm.u; l = pl.u;
+}
+
+// byte offset of element (row, k) inside one [ROWS][32] bf16 image
+__device__ __forceinline__ int img_off(int row, int k) {
+  return row * 64 + (((k >> 3) ^ ((row >> 2) & 3)) << 4) + ((k & 7) << 1);
+}
+
+template <int ROWS, bool KMAJOR>
+struct XTile {
+  static constexpr int NV = ROWS * XBK / 4 / NTHREADS;     // float4 per thread (ROWS/32)
+  static constexpr int IMG_BYTES = ROWS * 64;              // one bf16 image
+  static_assert(NV >= 1 && (KMAJOR || NV % 2 == 0), "tile too small");
+
+  // vector i of this thread covers: k-major: row rr, k = kk..kk+3;  x-major: rows rr..rr+3 at k = kk
+  __device__ __forceinline__ static void coords(int tid, int i, int& rr, int& kk) {
+    if (KMAJOR) {
+      const int v = tid + i * NTHREADS;
+      rr = v >> 3; kk = (v & 7) << 2;
+    } else {   // vectors 2p, 2p+1 of a thread are the same rows at k = 2q, 2q+1
+      const int p = tid + (i >> 1) * NTHREADS;
+      rr = (p % (ROWS / 4)) << 2;
+      kk = ((p / (ROWS / 4)) << 1) + (i & 1);
+    }
+  }
+
+  // Loop-invariant 32-bit element offsets of this thread's vectors relative to the tile origin
+  // (k-major: A + r0*ld + k0;  x-major: B + k0*ld + r0).  Rows beyond the matrix are clamped to the last
+  // valid row: they only feed output rows / columns that are never stored, so the k-loop needs no
+  // predication at all (the host dispatches here only when K % 32 == 0).
+  __device__ __forceinline__ static void prep(int (&off)[NV], long ld, int r0, int rmax, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int rr, kk;
+      coords(tid, i, rr, kk);
+      if (KMAJOR) off[i] = min(rr, rmax - 1 - r0) * (int)ld + kk;
+      else off[i] = kk * (int)ld + min(rr, rmax - 4 - r0);
+    }
+  }
+  __device__ __forceinline__ static void load(float4 (&r)[NV], const float* __restrict__ tile, const int (&off)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const float4*>(tile + off[i]);
+  }
+
+  // split into three bf16 images (hi, mid, lo at lds, lds + IMG, lds + 2*IMG)
+  __device__ __forceinline__ static void store(char* __restrict__ lds, const float4 (&r)[NV], int tid) {
+    if (KMAJOR) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int rr, kk;
+        coords(tid, i, rr, kk);
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2(r[i].x, r[i].y, h0, m0, l0);
+        split2(r[i].z, r[i].w, h1, m1, l1);
+        char* p = lds + img_off(rr, kk);
+        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(p + IMG_BYTES) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(p + 2 * IMG_BYTES) = make_uint2(l0, l1);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; i += 2) {
+        int rr, kk;
+        coords(tid, i, rr, kk);          // kk even; r[i] at k = kk, r[i+1] at k = kk + 1
+        const float a[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        const float b[4] = {r[i + 1].x, r[i + 1].y, r[i + 1].z, r[i + 1].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned h, m, l;
+          split2(a[j], b[j], h, m, l);
+          char* p = lds + img_off(rr + j, kk);
+          *reinterpret_cast<unsigned*>(p) = h;
+          *reinterpret_cast<unsigned*>(p + IMG_BYTES) = m;
+          *reinterpret_cast<unsigned*>(p + 2 * IMG_BYTES) = l;
+        }
+      }
+    }
+  }
+
+  // 8 consecutive k of `row` for MFMA k-step s (k = 16 s + 8 lh + j), image `which`
+  __device__ __forceinline__ static bf16x8 frag(const char* __restrict__ lds, int which, int row, int lh, int s) {
+    const int chunk = (2 * s + lh) ^ ((row >> 2) & 3);
+    return *reinterpret_cast<const bf16x8*>(lds + which * IMG_BYTES + row * 64 + (chunk << 4));
+  }
+};
+
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_kernel(const GemmK g) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  using TA = XTile<BM, AK>;
+  using TB = XTile<BN, BKM>;
+  constexpr int SMEM_BYTES = 3 * (TA::IMG_BYTES + TB::IMG_BYTES);
+  constexpr int SMEM_FLOATS = SMEM_BYTES / 4;
+  constexpr int EP = (BM * BN + SMEM_FLOATS - 1) / SMEM_FLOATS;
+  static_assert(EP == 1 || EP == 2 || EP == 4, "C tile needs too many epilogue passes");
+  static_assert((BM / 32) % EP == 0, "epilogue slabs must be whole 32-row tiles");
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_BYTES];
+  char* const As = smem_raw;
+  char* const Bs = smem_raw + 3 * TA::IMG_BYTES;
+
+  const int tid = threadIdx.x;
+  const int L = blockIdx.x;
+  int mt, nt;
+  if (g.swz) {
+    mt = (L / (8 * g.ntiles)) * 8 + (L & 7);
+    nt = (L >> 3) % g.ntiles;
+    if (mt >= g.mtiles) return;
+  } else {
+    mt = L / g.ntiles;
+    nt = L - mt * g.ntiles;
+  }
+  const int zz = blockIdx.z * gridDim.y + blockIdx.y;
+  if (zz >= g.ztotal) return;
+  const int z = zz / g.ksplit, ks = zz - z * g.ksplit;
+  const int z1 = z / g.zdiv, z2 = z - z1 * g.zdiv;
+  const float* __restrict__ A = g.A + z1 * g.sA1 + z2 * g.sA2;
+  const float* __restrict__ B = g.B + z1 * g.sB1 + z2 * g.sB2;
+  const long coff = z1 * g.sC1 + z2 * g.sC2 + (long)ks * g.sCk;
+  float* __restrict__ C = g.C + coff;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + XBK - 1) / XBK;
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int oa[TA::NV], ob[TB::NV];
+  TA::prep(oa, g.lda, m0, g.M, tid);
+  TB::prep(ob, g.ldb, n0, g.N, tid);
+  // uniform tile origins, advanced by one stage per iteration
+  const float* __restrict__ at = AK ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
+  const float* __restrict__ bt = BKM ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
+  const long astep = AK ? (long)XBK : (long)XBK * g.lda;
+  const long bstep = BKM ? (long)XBK : (long)XBK * g.ldb;
+
+  float4 ra[TA::NV], rb[TB::NV];
+  if (nkt > 0) {
+    TA::load(ra, at, oa);
+    TB::load(rb, bt, ob);
+  }
+  // (a second register set fetching two stages ahead was measured slower here: the extra 32 VGPRs cost
+  //  a resident wave, and three workgroups per CU already cover the load latency)
+  for (int kt = 0; kt < nkt; ++kt) {
+    TA::store(As, ra, tid);
+    TB::store(Bs, rb, tid);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      at += astep; bt += bstep;
+      TA::load(ra, at, oa);
+      TB::load(rb, bt, ob);
+    }
+#pragma unroll
+    for (int s = 0; s < XBK / 16; ++s) {
+      bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) af[i][w] = TA::frag(As, w, (wm * TM + i) * 32 + l31, lh, s);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) bf[j][w] = TB::frag(Bs, w, (wn * TN + j) * 32 + l31, lh, s);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x16 c = acc[i][j];        // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (same as the fp32 kernel's vector path; the host only dispatches here when g.cvec) ----
+  const bool drop_e = g.drop.on() && (g.drop_where & 4);
+  float* __restrict__ cs = reinterpret_cast<float*>(smem_raw);
+  constexpr int SLAB = BM / EP;
+  constexpr int VPR = BN / 4;
+  constexpr int NV4 = SLAB * BN / 4 / NTHREADS;
+  constexpr int RSTEP = NTHREADS / VPR;
+  static_assert(NV4 >= 1, "epilogue slab too small");
+  const int c4 = (tid % VPR) * 4, row0 = tid / VPR;
+  const int gn = n0 + c4;
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 bn4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias_mode == 1 && gn < g.N) bn4 = *reinterpret_cast<const float4*>(g.bias + gn);
+  const float* __restrict__ aux = g.aux ? g.aux + coff : nullptr;
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    if (e > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rt = (wm * TM + i) * 32;
+      if (rt / SLAB != e) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 32 + l31;
+        const int rb0 = rt - e * SLAB + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[(rb0 + (r & 3) + 8 * (r >> 2)) * BN + col] = acc[i][j][r];
+      }
+    }
+    __syncthreads();
+    if (gn < g.N) {
+#pragma unroll 4
+      for (int it = 0; it < NV4; ++it) {
+        const int row = row0 + it * RSTEP;
+        const int gm = m0 + e * SLAB + row;
+        if (gm >= g.M) break;
+        float4 v = *reinterpret_cast<const float4*>(cs + row * BN + c4);
+        v.x = fmaf(v.x, g.alpha, bn4.x); v.y = fmaf(v.y, g.alpha, bn4.y);
+        v.z = fmaf(v.z, g.alpha, bn4.z); v.w = fmaf(v.w, g.alpha, bn4.w);
+        if (g.bias_mode == 2) { const float bm = g.bias[gm]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+        if (g.epi_dact == RPDE_EPI_MULAUX) {
+          const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
+          v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
+        } else if (g.epi_dact) {
+          float s[4] = {1.f, 1.f, 1.f, 1.f};
+          if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+          const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
+          v.x *= dact_f(g.epi_dact, a.x * s[0]) * s[0];
+          v.y *= dact_f(g.epi_dact, a.y * s[1]) * s[1];
+          v.z *= dact_f(g.epi_dact, a.z * s[2]) * s[2];
+          v.w *= dact_f(g.epi_dact, a.w * s[3]) * s[3];
+        }
+        float4* cp = reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn);
+        if (g.accumulate) { const float4 o = *cp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (g.write_act) {
+          float s[4] = {1.f, 1.f, 1.f, 1.f};
+          if (drop_e && !g.epi_dact) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+          v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
+          if (g.aux_out) {
+            float4 dv;
+            act_both(g.write_act, v.x, v.x, dv.x); act_both(g.write_act, v.y, v.y, dv.y);
+            act_both(g.write_act, v.z, v.z, dv.z); act_both(g.write_act, v.w, v.w, dv.w);
+            dv.x *= s[0]; dv.y *= s[1]; dv.z *= s[2]; dv.w *= s[3];
+            *reinterpret_cast<float4*>(g.aux_out + coff + (long)gm * g.ldc + gn) = dv;
+          } else {
+            v.x = act_f(g.write_act, v.x); v.y = act_f(g.write_act, v.y);
+            v.z = act_f(g.write_act, v.z); v.w = act_f(g.write_act, v.w);
+          }
+        }
+        *cp = v;
+        csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+      }
+    }
+  }
+  if (g.colsum) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(cs + row0 * BN + c4) = csum;
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.N) {
+      float t = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < RSTEP; ++rr) t += cs[rr * BN + tid];
+      g.colsum[(long)mt * g.N + n0 + tid] = t;
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_x3_layout(const GemmK& g, bool ak, bool bk, dim3 grid, hipStream_t st) {
+  if (ak && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true>), grid, dim3(NTHREADS), 0, st, g);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, false>), grid, dim3(NTHREADS), 0, st, g);
+  else if (!ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, false>), grid, dim3(NTHREADS), 0, st, g);
+  else hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, true>), grid, dim3(NTHREADS), 0, st, g);
+}
+
+bool bf16x3_supports(int bm, int bn) { return (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128); }
+
+int launch_bf16x3(const GemmK& g, int bm, int bn, bool ak, bool bk, dim3 grid, hipStream_t st) {
+  if (bm == 128 && bn == 128) launch_x3_layout<2, 2, 2, 2>(g, ak, bk, grid, st);
+  else if (bm == 128 && bn == 64) launch_x3_layout<4, 1, 1, 2>(g, ak, bk, grid, st);
+  else if (bm == 64 && bn == 128) launch_x3_layout<1, 4, 2, 1>(g, ak, bk, grid, st);
+  else { set_error("bf16x3: unsupported tile %dx%d", bm, bn); return RPDE_ERR_ARG; }
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+}  // namespace rpde

@@ -73,6 +73,17 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   RPDE_CHECK_ARG(!d.colsum || (g.cvec && BMc == 128 && d.batch == 1 && d.ksplit == 1),
                  "gemm: colsum needs the vector epilogue, M > 64 and a single un-split problem");
 
+  // exact-product split-bf16 path (fp32 in / out / accumulate, products via 3-way bf16 splitting on the
+  // bf16 matrix pipe): every plain vector GEMM on a supported tile.  RPDE_SPLIT_BF16=0 forces the
+  // native fp32 MFMA kernels.
+  static const bool split_on = [] { const char* e = getenv("RPDE_SPLIT_BF16"); return !(e && e[0] == '0'); }();
+  // (x-major operands need a transposing LDS staging that costs more than it saves: measured slower
+  //  than the fp32 kernel, so only NT problems go this way; RPDE_SPLIT_BF16=2 sends everything)
+  static const bool split_all = [] { const char* e = getenv("RPDE_SPLIT_BF16"); return e && e[0] == '2'; }();
+  if (split_on && vec && g.cvec && pro == 0 && d.K >= 32 && d.K % 32 == 0 && d.lda < (1L << 24) && d.ldb < (1L << 24) &&
+      ((ak && bk) || split_all) && bf16x3_supports(BMc, BNc))
+    return launch_bf16x3(g, BMc, BNc, ak, bk, grid, st);
+
   if (ak && bk) return launch_nt(g, BMc, BNc, pro, vec, grid, st);
   if (ak && !bk) return launch_nn(g, BMc, BNc, pro, vec, grid, st);
   if (!ak && !bk) return launch_tn(g, BMc, BNc, pro, vec, grid, st);

@@ -546,6 +546,10 @@ inline int launch_layout_impl(const GemmK& g, int bm, int bn, int pro, bool vec,
   return RPDE_OK;
 }
 
+// split-bf16 path (gemm_bf16x3.hip)
+bool bf16x3_supports(int bm, int bn);
+int launch_bf16x3(const GemmK& g, int bm, int bn, bool ak, bool bk, dim3 grid, hipStream_t st);
+
 int launch_nt(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st);  // A k-major, B k-major
 int launch_nn(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st);  // A k-major, B x-major
 int launch_tn(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st);  // A x-major, B x-major

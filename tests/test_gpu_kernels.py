@@ -213,3 +213,19 @@ def test_gemm_writes_activation_and_derivative_once(gpu_device):
     _lib.check(lib.rpde_gemm_f32(C.byref(e), _lib.stream_ptr()), "gemm")
     ref = (G.double() @ W2.double()) * dv
     assert float((gx.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+
+
+def test_native_fp32_mfma_path_stays_green(gpu_device):
+    """The default dispatch sends NT problems to the split-bf16 kernel; one child process re-runs the
+    kernel and golden parity tests with RPDE_SPLIT_BF16=0 so the native fp32-MFMA kernels stay covered."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("RPDE_SPLIT_BF16") == "0":
+        pytest.skip("already the native-fp32 leg")
+    env = dict(os.environ, RPDE_SPLIT_BF16="0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_kernels.py"),
+                        os.path.join(here, "test_gpu_golden.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
