@@ -93,20 +93,31 @@ def time_ff_gemm(B, device, iters=20):
         d.batch, d.zdiv, d.ksplit, d.alpha = 1, 1, 1, 1.0
         return d
 
+    def presplit(wm, kmajor, n, k):
+        # what rpde_feedforward_fwd/bwd do once per call: the weight as three bf16 images
+        lib = _lib.load()
+        img = torch.empty(lib.rpde_split_weights_bytes(n, k), dtype=torch.uint8, device=device)
+        _lib.check(lib.rpde_split_weights(wm.data_ptr(), kmajor, wm.shape[1], n, k, img.data_ptr(), _lib.stream_ptr()),
+                   "split_weights")
+        return img
+
     d = base()                                           # forward
     d.A, d.B, d.C = h1.data_ptr(), w.data_ptr(), h2.data_ptr()
     d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = P, N, K, 1, 1
     d.lda, d.ldb, d.ldc = K, K, N
     d.bias, d.bias_mode, d.write_act, d.aux_out = b.data_ptr(), 1, 1, d2.data_ptr()
     d.drop_p, d.drop_seed, d.drop_ld, d.drop_where = 0.1, 12345, N, 4
+    wimg = presplit(w, 1, N, K)
+    d.b_split = wimg.data_ptr()
     ms = _time_gemm(d, iters)
     extra = []
     e = base()                                           # backward-data: gx = (g @ W) * d + per-tile column sums
     cs = torch.empty(((P + 127) // 128) * K, device=device)
-    wt = w.t().contiguous()                              # training transposes the 256x256 weight once per call
-    e.A, e.B, e.C = h2.data_ptr(), wt.data_ptr(), h1.data_ptr()
-    e.M, e.N, e.K, e.a_kmajor, e.b_kmajor = P, K, N, 1, 1
-    e.lda, e.ldb, e.ldc = N, N, K
+    wtimg = presplit(w, 0, K, N)                         # W [out,in] is x-major for this product
+    e.A, e.B, e.C = h2.data_ptr(), w.data_ptr(), h1.data_ptr()
+    e.M, e.N, e.K, e.a_kmajor, e.b_kmajor = P, K, N, 1, 0
+    e.lda, e.ldb, e.ldc = N, K, K
+    e.b_split = wtimg.data_ptr()
     e.epi_dact, e.aux, e.ldaux, e.colsum = 100, d2.data_ptr(), K, cs.data_ptr()
     t = _time_gemm(e, max(5, iters // 2))
     byt = 4.0 * P * (N + 2 * K)                          # read g, read d, write gx
@@ -212,6 +223,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steps-only", action="store_true",
+                    help="profiling aid: stop after the timed training steps (no kernel microbenchmarks, no parity leg)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -274,7 +287,10 @@ def main():
     mean_loss = float(loss_sum.item()) / max(1, args.steps + args.warmup)
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
 
-    if rank == 0:
+    if rank == 0 and args.steps_only:
+        print(json.dumps({"steps_only": True, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "samples_per_s": round(B * world * args.steps / elapsed, 3)}), flush=True)
+    elif rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
         g_ms, g_tf, g_flops, g_extra, g_bytes = time_ff_gemm(B, device)

@@ -95,8 +95,18 @@ typedef struct {
    * once per element, u = dropout(acc+bias): C = act(u), aux_out = act'(u) * dropscale -- so every
    * consumer of the hidden activation and of its derivative is a plain GEMM (drop_where bit 2) */
   float* aux_out;
+  /* optional accelerator for a B operand shared by the whole batch (a weight matrix): the images written by
+   * rpde_split_weights for this B (same N, K).  Results are bit-identical with and without it; B must
+   * still be valid (the native fp32 kernels use it when the split-bf16 path does not apply). */
+  const void* b_split;
 } rpde_gemm_desc;
 int rpde_gemm_f32(const rpde_gemm_desc* d, void* stream);
+
+/* Pre-split a weight operand for the split-bf16 GEMM path: w is [N,K] (kmajor=1, row stride ld) or [K,N]
+ * (kmajor=0); out receives rpde_split_weights_bytes(N,K) bytes (0: K is not a multiple of 32, no such
+ * path): three bf16 images hi/mid/lo with w = hi+mid+lo exactly, laid out as the kernel's LDS stages. */
+size_t rpde_split_weights_bytes(int N, int K);
+int rpde_split_weights(const float* w, int kmajor, int64_t ld, int N, int K, void* out, void* stream);
 
 /* ---- FSpectralConv1d.forward_fourier  (models/spectral_convolution.py:158-204)
  * x,out [B,n,C] channels-last; w [C,C,K,2]; keff=min(K,n/2+1) is clamped here
@@ -174,7 +184,10 @@ typedef struct {
   const float* const* biases;          /* [n_layers] b_l [out_l]                     */
   const float* ln_gamma; const float* ln_beta;
 } rpde_ff_params;
-size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers);
+size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers);      /* backward */
+/* forward scratch (optional: ws may be NULL; with it each weight is pre-split once per call for the
+ * split-bf16 GEMMs -- faster, bit-identical output) */
+size_t rpde_feedforward_fwd_ws_bytes(int dim, int factor, int n_layers);
 int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual,
                          float* const* hs, float* const* ds, float* z_last, float* out, int64_t P,
                          void* ws, size_t ws_bytes, void* stream);

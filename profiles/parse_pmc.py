@@ -31,7 +31,7 @@ def main(fetch_dir, write_dir, B, out):
                      "hbm_bytes_per_launch": (2 * f + w) * 1024}
     # dominant kernel = split-bf16 NT 128x128 (its epilogue writes h and d); pmc_target.py launches that
     # instantiation for the forward and for the backward-data GEMM: take the larger (forward, 3 P*256 floats)
-    dom = [k for k in res if "gemm_bf16x3_kernel<2, 2, 2, 2, true, true>" in k]
+    dom = [k for k in res if "gemm_bf16x3_kernel<2, 2, 2, 2, true, true" in k]
     blob = json.load(open(out)) if os.path.exists(out) else {}
     if dom:
         blob.setdefault("ff_gemm_256x256", {})[f"B{B}"] = max(res[k]["hbm_bytes_per_launch"] for k in dom)

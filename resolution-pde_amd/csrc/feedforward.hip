@@ -9,6 +9,7 @@
 // training step, costing 25-30 % of each fused GEMM; see profiles/r01_b_kernel_bench.txt.)
 #include "rpde_internal.h"
 #include "pointwise.h"
+#include "gemm_kernel.h"
 
 namespace rpde {
 
@@ -34,11 +35,19 @@ static inline int wgrad_split(long P, int out_f, int in_f) {
 
 // y[P,out] = act_in(x)[P,in] . W[out,in]^T + b
 // act_out != 0: y = act(dropout(z)) and, if dy, dy = act'(dropout(z)) * dropscale (mask of THIS layer's output)
+// wimg: optional scratch of split_bytes(out_f, in_f): the weight is split into bf16 images once per call
+// instead of once per workgroup (same bits out; see gemm_bf16x3.hip)
+static inline bool worth_presplit(long P, int n, int k) { return P >= 1024 && k % 32 == 0 && n > 32; }
 static int linear_fwd_impl(const float* x, const float* w, const float* b, float* y, long P, int in_f, int out_f,
-                           int act_out, float* dy, float drop_p, uint64_t drop_seed, hipStream_t st) {
+                           int act_out, float* dy, float drop_p, uint64_t drop_seed, hipStream_t st,
+                           void* wimg = nullptr) {
   rpde_gemm_desc d = gemm_desc();
   d.A = x; d.a_kmajor = 1; d.lda = in_f;
   d.B = w; d.b_kmajor = 1; d.ldb = in_f;
+  if (wimg && worth_presplit(P, out_f, in_f)) {
+    RPDE_TRY(split_weights(w, 1, in_f, out_f, in_f, wimg, st));
+    d.b_split = wimg;
+  }
   d.C = y; d.ldc = out_f;
   d.M = (int)P; d.N = out_f; d.K = in_f;
   d.bias = b; d.bias_mode = b ? 1 : 0;
@@ -79,17 +88,16 @@ static inline bool can_fuse_colsum(const float* gy, const float* w, const float*
 }
 
 // gx[P,in] = (gy[P,out] . W[out,in]) (* dstored[P,in] when given: the derivative saved by the forward epilogue)
-// wt: optional scratch of in_f*out_f floats: W is transposed into it first so that both operands are
-// k-major and the GEMM can take the split-bf16 path
+// wimg: optional scratch of split_bytes(in_f, out_f): W (x-major here) is split into k-major bf16 images
+// first, which is what lets this GEMM take the split-bf16 path at all
 static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f,
-                             const float* dstored, float* colsum_slab, hipStream_t st, float* wt = nullptr) {
+                             const float* dstored, float* colsum_slab, hipStream_t st, void* wimg = nullptr) {
   rpde_gemm_desc d = gemm_desc();
   d.A = gy; d.a_kmajor = 1; d.lda = out_f;
-  if (wt) {
-    RPDE_TRY(rpde_transpose_cs(w, wt, 1, out_f, in_f, 1, st));     // [out,in] -> [in,out]
-    d.B = wt; d.b_kmajor = 1; d.ldb = out_f;
-  } else {
-    d.B = w; d.b_kmajor = 0; d.ldb = in_f;
+  d.B = w; d.b_kmajor = 0; d.ldb = in_f;
+  if (wimg && worth_presplit(P, in_f, out_f)) {
+    RPDE_TRY(split_weights(w, 0, in_f, in_f, out_f, wimg, st));
+    d.b_split = wimg;
   }
   d.C = gx; d.ldc = in_f;
   d.M = (int)P; d.N = in_f; d.K = out_f;
@@ -97,6 +105,9 @@ static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P,
   d.colsum = colsum_slab;
   return launch_gemm(d, st);
 }
+
+// scratch for one layer's split weight images (floats), any layer of a FeedForward with hidden width hid
+static size_t ff_wimg_floats(int hid) { return (split_bytes(hid, ((hid + 31) / 32) * 32) + 3) / 4; }
 
 static size_t wgrad_ws_floats(long P, int in_f, int out_f) {
   const int S = wgrad_split(P, out_f, in_f);
@@ -123,7 +134,11 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
   if (t > small) small = t;
   const size_t c = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
   if (c > small) small = c;
-  return 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small) + arena_bytes((size_t)hid * hid);
+  return 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small) + arena_bytes(ff_wimg_floats(hid));
+}
+
+size_t rpde_feedforward_fwd_ws_bytes(int dim, int factor, int n_layers) {
+  return arena_bytes(ff_wimg_floats(n_layers > 1 ? dim * factor : dim));
 }
 
 int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs,
@@ -134,15 +149,19 @@ int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* r
   RPDE_CHECK_ARG(P < (1L << 31), "feedforward_fwd: too many points for one call");
   RPDE_CHECK_ARG(p->dropout_p >= 0.f && p->dropout_p < 1.f, "feedforward_fwd: dropout %f", p->dropout_p);
   hipStream_t st = as_stream(stream);
-  (void)ws; (void)ws_bytes;
   const int L = p->n_layers;
+  // optional scratch (rpde_feedforward_fwd_ws_bytes): weights are pre-split once per call; without it the
+  // GEMMs split them per workgroup (slower, same bits)
+  Arena ar(ws, ws_bytes);
+  void* wimg = ws ? ar.take(ff_wimg_floats(L > 1 ? p->dim * p->factor : p->dim)) : nullptr;
+  if (!ar.ok()) wimg = nullptr;
   for (int l = 0; l < L; ++l) {
     const bool last = l == L - 1;
     RPDE_CHECK_ARG(p->weights[l] && (last || hs[l]), "feedforward_fwd: null layer %d buffers", l);
     const float* in = l == 0 ? x : hs[l - 1];
     RPDE_TRY(linear_fwd_impl(in, p->weights[l], p->biases ? p->biases[l] : nullptr, last ? z_last : hs[l], P, ff_in(p, l),
                              ff_out(p, l), last ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU, (last || !ds) ? nullptr : ds[l],
-                             p->dropout_p, layer_seed(p->seed, l), st));
+                             p->dropout_p, layer_seed(p->seed, l), st, wimg));
   }
   return ff_tail_fwd(z_last, residual, out, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
                      make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, st);
@@ -168,7 +187,7 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   if (ff_tail_bwd_ws_floats(P, p->dim) > small_n) small_n = ff_tail_bwd_ws_floats(P, p->dim);
   if ((size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid > small_n) small_n = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
   float* small = ar.take(small_n);
-  float* wt = ar.take((size_t)hid * hid);
+  void* wt = ar.take(ff_wimg_floats(hid));
   if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
 
   // tail: d(out) -> dz_{L-1}, d(gamma), d(beta) and, fused, the last layer's bias gradient

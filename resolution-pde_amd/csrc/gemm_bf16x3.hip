@@ -126,8 +126,28 @@ struct XTile {
   }
 };
 
-template <int WM, int WN, int TM, int TN, bool AK, bool BKM>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_kernel(const GemmK g) {
+// one stage of a pre-split operand: NBI 16-byte chunks per image per thread, straight copies
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int NBI>
+__device__ __forceinline__ void bimg_load(u32x4 (&r)[3 * NBI], const char* __restrict__ p, long img_stride) {
+#pragma unroll
+  for (int i = 0; i < 3 * NBI; ++i)
+    r[i] = *reinterpret_cast<const u32x4*>(p + (i / NBI) * img_stride + (i % NBI) * (NTHREADS * 16));
+}
+template <int NBI>
+__device__ __forceinline__ void bimg_store(char* __restrict__ lds, const u32x4 (&r)[3 * NBI], int img_bytes) {
+#pragma unroll
+  for (int i = 0; i < 3 * NBI; ++i)
+    *reinterpret_cast<u32x4*>(lds + (i / NBI) * img_bytes + (i % NBI) * (NTHREADS * 16)) = r[i];
+}
+
+// BIMG: the B operand arrives pre-split (rpde_split_weights: [K/32][3][Npad][32] bf16 images whose rows are
+// already chunk-swizzled), so a B stage is a straight 16-byte copy into LDS and costs no VALU work.  Every
+// workgroup needs the same weight tile, so splitting it once per call instead of once per workgroup
+// removes half of the loop's vector instructions (MFMA and VALU issue serially on a SIMD, measured in
+// profiles/ubench/overlap.hip).
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM, bool BIMG = false>
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
   using TA = XTile<BM, AK>;
@@ -177,9 +197,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_kernel(const GemmK g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  constexpr int NBI = BIMG ? BN * 4 / NTHREADS : 1;       // 16-byte chunks per image per thread
+  static_assert(!BIMG || (BKM && NBI >= 1), "pre-split B is k-major");
   int oa[TA::NV], ob[TB::NV];
   TA::prep(oa, g.lda, m0, g.M, tid);
-  TB::prep(ob, g.ldb, n0, g.N, tid);
+  if (!BIMG) TB::prep(ob, g.ldb, n0, g.N, tid);
+  const char* __restrict__ bimg = g.Bimg + ((long)(kbeg / XBK) * 3 * g.npad + n0) * 64 + tid * 16;
+  const long bimg_step = 3L * g.npad * 64;
+  u32x4 rbi[3 * NBI];
   // uniform tile origins, advanced by one stage per iteration
   const float* __restrict__ at = AK ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
   const float* __restrict__ bt = BKM ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
@@ -189,18 +214,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_kernel(const GemmK g) {
   float4 ra[TA::NV], rb[TB::NV];
   if (nkt > 0) {
     TA::load(ra, at, oa);
-    TB::load(rb, bt, ob);
+    if (BIMG) bimg_load<NBI>(rbi, bimg, (long)g.npad * 64); else TB::load(rb, bt, ob);
   }
   // (a second register set fetching two stages ahead was measured slower here: the extra 32 VGPRs cost
   //  a resident wave, and three workgroups per CU already cover the load latency)
   for (int kt = 0; kt < nkt; ++kt) {
     TA::store(As, ra, tid);
-    TB::store(Bs, rb, tid);
+    if (BIMG) bimg_store<NBI>(Bs + tid * 16, rbi, TB::IMG_BYTES); else TB::store(Bs, rb, tid);
     __syncthreads();
     if (kt + 1 < nkt) {
-      at += astep; bt += bstep;
+      at += astep; bt += bstep; bimg += bimg_step;
       TA::load(ra, at, oa);
-      TB::load(rb, bt, ob);
+      if (BIMG) bimg_load<NBI>(rbi, bimg, (long)g.npad * 64); else TB::load(rb, bt, ob);
     }
 #pragma unroll
     for (int s = 0; s < XBK / 16; ++s) {
@@ -319,10 +344,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16x3_kernel(const GemmK g) {
 
 template <int WM, int WN, int TM, int TN>
 static void launch_x3_layout(const GemmK& g, bool ak, bool bk, dim3 grid, hipStream_t st) {
-  if (ak && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true>), grid, dim3(NTHREADS), 0, st, g);
+  if (ak && bk && g.Bimg) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(NTHREADS), 0, st, g);
+  else if (ak && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true>), grid, dim3(NTHREADS), 0, st, g);
   else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, false>), grid, dim3(NTHREADS), 0, st, g);
   else if (!ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, false>), grid, dim3(NTHREADS), 0, st, g);
   else hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, true>), grid, dim3(NTHREADS), 0, st, g);
+}
+
+// fp32 weights [N,K] (k-major, ld) or [K,N] (x-major) -> [K/32][3][Npad][32] bf16 images, 16-byte chunks of
+// each 64-byte row XOR-swizzled with (row>>2)&3 (= the LDS image of a stage), pad rows zero
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, int kmajor, long ld, int N, int K,
+                                                       int npad, char* __restrict__ out) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int kchunks = K / 8;
+  if (t >= (long)npad * kchunks) return;
+  const int n = (int)(t % npad), kc = (int)(t / npad);     // consecutive threads: consecutive rows
+  const int k0 = kc * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = n < N ? (kmajor ? w[(long)n * ld + k0 + j] : w[(long)(k0 + j) * ld + n]) : 0.f;
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+  const int kt = k0 / XBK, c = (k0 % XBK) / 8;
+  char* p = out + ((long)kt * 3 * npad + n) * 64 + ((c ^ ((n >> 2) & 3)) << 4);
+  *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+  *reinterpret_cast<uint4*>(p + (long)npad * 64) = make_uint4(m[0], m[1], m[2], m[3]);
+  *reinterpret_cast<uint4*>(p + 2L * npad * 64) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+int split_npad(int N) { return ((N + 127) / 128) * 128; }
+size_t split_bytes(int N, int K) { return (size_t)(K / XBK) * 3 * split_npad(N) * 64; }
+
+int split_weights(const float* w, int kmajor, long ld, int N, int K, void* out, hipStream_t st) {
+  RPDE_CHECK_ARG(w && out && N > 0 && K >= XBK && K % XBK == 0, "split_weights: K must be a positive multiple of 32 (got N=%d K=%d)", N, K);
+  RPDE_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0, "split_weights: output must be 16-byte aligned");
+  const int npad = split_npad(N);
+  const long threads = (long)npad * (K / 8);
+  hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, w, kmajor, ld, N, K, npad,
+                     static_cast<char*>(out));
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
 }
 
 bool bf16x3_supports(int bm, int bn) { return (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128); }
@@ -337,3 +399,8 @@ int launch_bf16x3(const GemmK& g, int bm, int bn, bool ak, bool bk, dim3 grid, h
 }
 
 }  // namespace rpde
+
+extern "C" size_t rpde_split_weights_bytes(int N, int K) { return K % rpde::XBK == 0 ? rpde::split_bytes(N, K) : 0; }
+extern "C" int rpde_split_weights(const float* w, int kmajor, int64_t ld, int N, int K, void* out, void* stream) {
+  return rpde::split_weights(w, kmajor, (long)ld, N, K, out, rpde::as_stream(stream));
+}

@@ -68,6 +68,7 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
            (!(d.bias && d.bias_mode == 1) || al16(d.bias)) && (!(g.drop.on() && (d.drop_where & 4)) || d.drop_ld % 4 == 0);
   g.colsum = d.colsum;
   g.aux_out = d.aux_out;
+  g.Bimg = nullptr; g.npad = 0;
   RPDE_CHECK_ARG(!d.aux_out || d.write_act, "gemm: aux_out needs write_act");
   if (d.aux_out) g.cvec = g.cvec && al16(d.aux_out);
   RPDE_CHECK_ARG(!d.colsum || (g.cvec && BMc == 128 && d.batch == 1 && d.ksplit == 1),
@@ -80,9 +81,16 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   // (x-major operands need a transposing LDS staging that costs more than it saves: measured slower
   //  than the fp32 kernel, so only NT problems go this way; RPDE_SPLIT_BF16=2 sends everything)
   static const bool split_all = [] { const char* e = getenv("RPDE_SPLIT_BF16"); return e && e[0] == '2'; }();
+  // a pre-split B (rpde_split_weights) is k-major whatever the layout of the fp32 original
+  const bool bimg = d.b_split && ak && d.sB1 == 0 && d.sB2 == 0 && g.kchunk % 32 == 0;
   if (split_on && vec && g.cvec && pro == 0 && d.K >= 32 && d.K % 32 == 0 && d.lda < (1L << 24) && d.ldb < (1L << 24) &&
-      ((ak && bk) || split_all) && bf16x3_supports(BMc, BNc))
-    return launch_bf16x3(g, BMc, BNc, ak, bk, grid, st);
+      ((ak && (bk || bimg)) || split_all) && bf16x3_supports(BMc, BNc)) {
+    if (bimg) {
+      g.Bimg = static_cast<const char*>(d.b_split);
+      g.npad = split_npad(d.N);
+    }
+    return launch_bf16x3(g, BMc, BNc, ak, bk || bimg, grid, st);
+  }
 
   if (ak && bk) return launch_nt(g, BMc, BNc, pro, vec, grid, st);
   if (ak && !bk) return launch_nn(g, BMc, BNc, pro, vec, grid, st);

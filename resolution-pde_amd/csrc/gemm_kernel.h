@@ -58,6 +58,8 @@ struct GemmK {
   int cvec;          // C / aux / bias allow 16-byte row accesses: LDS-staged epilogue
   float* colsum;     // optional [mtiles][N] per-M-tile column sums of the stored C
   float* aux_out;    // optional act'(u)*dropscale beside C = act(u)
+  const char* Bimg;  // optional pre-split B (split_weights), split-bf16 NT path only
+  int npad;          // rows per image of Bimg
 };
 
 template <int ROWS, int BK, bool KMAJOR, bool VEC, bool PRO>
@@ -548,6 +550,9 @@ inline int launch_layout_impl(const GemmK& g, int bm, int bn, int pro, bool vec,
 
 // split-bf16 path (gemm_bf16x3.hip)
 bool bf16x3_supports(int bm, int bn);
+int split_npad(int N);
+size_t split_bytes(int N, int K);
+int split_weights(const float* w, int kmajor, long ld, int N, int K, void* out, hipStream_t st);
 int launch_bf16x3(const GemmK& g, int bm, int bn, bool ak, bool bk, dim3 grid, hipStream_t st);
 
 int launch_nt(const GemmK& g, int bm, int bn, int pro, bool vec, dim3 grid, hipStream_t st);  // A k-major, B k-major

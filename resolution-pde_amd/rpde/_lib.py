@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64),
         ("write_act", C.c_int), ("drop_where", C.c_int),
-        ("colsum", C.c_void_p), ("aux_out", C.c_void_p),
+        ("colsum", C.c_void_p), ("aux_out", C.c_void_p), ("b_split", C.c_void_p),
     ]
 
 
@@ -70,6 +70,8 @@ _SIGNATURES = {
     "rpde_plan_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "rpde_plan_tables": (_I, [_P, _P, _P]),
     "rpde_gemm_f32": (_I, [C.POINTER(GemmDesc), _P]),
+    "rpde_split_weights_bytes": (C.c_size_t, [_I, _I]),
+    "rpde_split_weights": (_I, [_P, _I, C.c_int64, _I, _I, _P, _P]),
     "rpde_fspectral1d_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rpde_fspectral1d_spec_elems": (_Z, [_I, _I, _I, _I]),
     "rpde_fspectral1d_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
@@ -86,6 +88,7 @@ _SIGNATURES = {
     "rpde_spectral2d_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_spectral2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_feedforward_ws_bytes": (_Z, [_L, _I, _I, _I]),
+    "rpde_feedforward_fwd_ws_bytes": (_Z, [_I, _I, _I]),
     "rpde_feedforward_fwd": (_I, [C.POINTER(FFParams), _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
     "rpde_feedforward_bwd": (_I, [C.POINTER(FFParams), _P, _PP, _PP, _P, _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
     "rpde_linear_ws_bytes": (_Z, [_L, _I, _I]),

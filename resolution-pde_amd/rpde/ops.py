@@ -151,8 +151,10 @@ class _FeedForward(torch.autograd.Function):
         wa, ba, ha, da = ptr_array(ws_), ptr_array(bs_), ptr_array(hs or [None]), ptr_array(ds or [None])
         fp = _lib.FFParams(L, dim, factor, int(layer_norm), eps, p_drop, seed, post_act,
                            C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta))
+        nws = lib.rpde_feedforward_fwd_ws_bytes(dim, factor, L)
+        ws = workspace(nws, x.device)
         check(lib.rpde_feedforward_fwd(C.byref(fp), ptr(x2), ptr(res2), C.cast(ha, C.POINTER(C.c_void_p)),
-                                       C.cast(da, C.POINTER(C.c_void_p)), ptr(z_last), ptr(out), P, None, 0,
+                                       C.cast(da, C.POINTER(C.c_void_p)), ptr(z_last), ptr(out), P, ws.data_ptr(), nws,
                                        stream_ptr()), "feedforward_fwd")
         ctx.cfg = cfg
         ctx.has_res = residual is not None

@@ -215,6 +215,58 @@ def test_gemm_writes_activation_and_derivative_once(gpu_device):
     assert float((gx.cpu().double() - ref).norm() / ref.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,b_k", [(4096, 256, 256, 1), (4096, 256, 256, 0), (1500, 64, 256, 1), (1100, 200, 64, 0),
+                                       (2048, 256, 96, 0)])
+def test_presplit_weight_operand_is_bit_identical(gpu_device, M, N, K, b_k):
+    """rpde_split_weights + rpde_gemm_desc.b_split: the weight is split into bf16 images once instead of in
+    every workgroup.  Same arithmetic, so C must match the un-pre-split launch bit for bit (k-major B) and
+    the float64 product to fp32-GEMM accuracy (either layout of the fp32 original)."""
+    from rpde import _lib
+    lib = _lib.load()
+    dev = gpu_device
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * torch.logspace(-3, 3, N)[:, None]      # wide dynamic range
+    Ad = A.to(dev)
+    Wd = (W if b_k else W.t()).contiguous().to(dev)                              # [N,K] or [K,N]
+    nbytes = lib.rpde_split_weights_bytes(N, K)
+    assert nbytes == (K // 32) * 3 * ((N + 127) // 128 * 128) * 64
+    img = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.rpde_split_weights(Wd.data_ptr(), b_k, K if b_k else N, N, K, img.data_ptr(), _lib.stream_ptr()), "split")
+
+    def run(use_img):
+        out = torch.empty(M, N, device=dev)
+        d = _lib.GemmDesc()
+        d.A, d.B, d.C = Ad.data_ptr(), Wd.data_ptr(), out.data_ptr()
+        d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = M, N, K, 1, b_k
+        d.lda, d.ldb, d.ldc, d.batch, d.zdiv, d.ksplit, d.alpha = K, (K if b_k else N), N, 1, 1, 1, 1.0
+        if use_img:
+            d.b_split = img.data_ptr()
+        _lib.check(lib.rpde_gemm_f32(C.byref(d), _lib.stream_ptr()), "gemm")
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    with_img, without = run(True), run(False)
+    ref = A.double() @ W.double().t()
+    assert float((with_img.double() - ref).norm() / ref.norm()) < GEMM_TOL
+    assert float((without.double() - ref).norm() / ref.norm()) < GEMM_TOL
+    import os
+    if b_k and os.environ.get("RPDE_SPLIT_BF16") != "0":
+        assert torch.equal(with_img, without)
+    # the three images reconstruct the weights exactly: hi + mid + lo == w in fp32
+    if K % 32 == 0:
+        npad = (N + 127) // 128 * 128
+        im = img.cpu().numpy().view(np.uint16).reshape(K // 32, 3, npad, 4, 8)
+        rows = np.arange(npad)
+        unsw = np.empty_like(im)
+        for c in range(4):                      # undo the chunk swizzle
+            unsw[:, :, rows, c, :] = im[:, :, rows, c ^ ((rows >> 2) & 3), :]
+        f = (unsw.astype(np.uint32) << 16).view(np.float32).reshape(K // 32, 3, npad, 32)
+        rec = (f[:, 0].astype(np.float64) + f[:, 1] + f[:, 2]).transpose(1, 0, 2).reshape(npad, K)
+        np.testing.assert_array_equal(rec[:N].astype(np.float32), W.numpy())
+        assert not rec[N:].any()
+
+
 def test_native_fp32_mfma_path_stays_green(gpu_device):
     """The default dispatch sends NT problems to the split-bf16 kernel; one child process re-runs the
     kernel and golden parity tests with RPDE_SPLIT_BF16=0 so the native fp32-MFMA kernels stay covered."""
