@@ -17,8 +17,8 @@
 // while a tile moves registers -> LDS; LDS holds three bf16 images per operand as [row][32 k] = 64-byte
 // rows whose 16-byte chunks are XOR-swizzled with (row>>2)&3, so the ds_read_b128 fragment reads
 // (lane = row, 8 consecutive k) are bank-conflict free without padding.  x-major operands (reduction
-// index slow in memory: weight gradients, backward-data weights) are transposed on the way into LDS:
-// each thread loads the same 4 rows at two adjacent k and writes packed (k, k+1) bf16 pairs.
+// index slow in memory: weight gradients, channels-last fields) keep their memory order in LDS and are
+// transposed by the read: ds_read_b64_tr_b16 (see XTile).
 // The epilogue is the fp32 kernel's (LDS-staged 16-byte rows, bias / activation+derivative / multiply by
 // stored derivative / accumulate / per-tile column sums).
 #include "gemm_kernel.h"
@@ -48,22 +48,32 @@ __device__ __forceinline__ int img_off(int row, int k) {
   return row * 64 + (((k >> 3) ^ ((row >> 2) & 3)) << 4) + ((k & 7) << 1);
 }
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// One operand stage in LDS: three bf16 images of ROWS x 32(k).
+//  k-major operand (k contiguous in memory): image rows are the operand's rows, [row][32 k] = 64-byte rows,
+//    16-byte chunks XOR-swizzled with (row>>2)&3; fragments are ds_read_b128 (lane = row, 8 consecutive k).
+//  x-major operand (k slow in memory: weight gradients, spectral fields): the image keeps the memory
+//    order, [k][ROWS] bf16 rows of 2*ROWS bytes, and the fragments come out of gfx950's transposing read
+//    ds_read_b64_tr_b16 (each group of 16 lanes fetches a 4(k) x 16(row) block and receives it column
+//    major), so the store side stays a plain vector write.  8-byte chunks are XOR-swizzled so that the four
+//    k-rows a half-wave reads land on different banks.
 template <int ROWS, bool KMAJOR>
 struct XTile {
   static constexpr int NV = ROWS * XBK / 4 / NTHREADS;     // float4 per thread (ROWS/32)
   static constexpr int IMG_BYTES = ROWS * 64;              // one bf16 image
-  static_assert(NV >= 1 && (KMAJOR || NV % 2 == 0), "tile too small");
+  static constexpr int CPR = ROWS / 4;                     // x-major: 8-byte chunks per k-row
+  static_assert(NV >= 1 && (ROWS == 64 || ROWS == 128), "unsupported tile");
+
+  __device__ __forceinline__ static int xswz(int k) { return ROWS == 128 ? ((k & 3) << 3) : (((k >> 1) & 1) << 3); }
+  // byte offset of 8-byte chunk c8 (operand rows 4 c8 .. 4 c8 + 3) of k-row k inside an x-major image
+  __device__ __forceinline__ static int xoff(int k, int c8) { return k * (2 * ROWS) + ((c8 ^ xswz(k)) << 3); }
 
   // vector i of this thread covers: k-major: row rr, k = kk..kk+3;  x-major: rows rr..rr+3 at k = kk
   __device__ __forceinline__ static void coords(int tid, int i, int& rr, int& kk) {
-    if (KMAJOR) {
-      const int v = tid + i * NTHREADS;
-      rr = v >> 3; kk = (v & 7) << 2;
-    } else {   // vectors 2p, 2p+1 of a thread are the same rows at k = 2q, 2q+1
-      const int p = tid + (i >> 1) * NTHREADS;
-      rr = (p % (ROWS / 4)) << 2;
-      kk = ((p / (ROWS / 4)) << 1) + (i & 1);
-    }
+    const int v = tid + i * NTHREADS;
+    if (KMAJOR) { rr = v >> 3; kk = (v & 7) << 2; }
+    else { kk = v / CPR; rr = (v % CPR) << 2; }
   }
 
   // Loop-invariant 32-bit element offsets of this thread's vectors relative to the tile origin
@@ -86,43 +96,42 @@ struct XTile {
 
   // split into three bf16 images (hi, mid, lo at lds, lds + IMG, lds + 2*IMG)
   __device__ __forceinline__ static void store(char* __restrict__ lds, const float4 (&r)[NV], int tid) {
-    if (KMAJOR) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        int rr, kk;
-        coords(tid, i, rr, kk);
-        unsigned h0, m0, l0, h1, m1, l1;
-        split2(r[i].x, r[i].y, h0, m0, l0);
-        split2(r[i].z, r[i].w, h1, m1, l1);
-        char* p = lds + img_off(rr, kk);
-        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(p + IMG_BYTES) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(p + 2 * IMG_BYTES) = make_uint2(l0, l1);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NV; i += 2) {
-        int rr, kk;
-        coords(tid, i, rr, kk);          // kk even; r[i] at k = kk, r[i+1] at k = kk + 1
-        const float a[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-        const float b[4] = {r[i + 1].x, r[i + 1].y, r[i + 1].z, r[i + 1].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          unsigned h, m, l;
-          split2(a[j], b[j], h, m, l);
-          char* p = lds + img_off(rr + j, kk);
-          *reinterpret_cast<unsigned*>(p) = h;
-          *reinterpret_cast<unsigned*>(p + IMG_BYTES) = m;
-          *reinterpret_cast<unsigned*>(p + 2 * IMG_BYTES) = l;
-        }
-      }
+    for (int i = 0; i < NV; ++i) {
+      int rr, kk;
+      coords(tid, i, rr, kk);
+      unsigned h0, m0, l0, h1, m1, l1;
+      split2(r[i].x, r[i].y, h0, m0, l0);
+      split2(r[i].z, r[i].w, h1, m1, l1);
+      char* p = lds + (KMAJOR ? img_off(rr, kk) : xoff(kk, rr >> 2));
+      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p + IMG_BYTES) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(p + 2 * IMG_BYTES) = make_uint2(l0, l1);
     }
   }
 
-  // 8 consecutive k of `row` for MFMA k-step s (k = 16 s + 8 lh + j), image `which`
-  __device__ __forceinline__ static bf16x8 frag(const char* __restrict__ lds, int which, int row, int lh, int s) {
-    const int chunk = (2 * s + lh) ^ ((row >> 2) & 3);
-    return *reinterpret_cast<const bf16x8*>(lds + which * IMG_BYTES + row * 64 + (chunk << 4));
+  // per-lane byte offset (inside an image) of the fragment of 32-row tile `t` at k-step 0; fragments of
+  // the other k-step / images sit at compile-time distances from it
+  __device__ __forceinline__ static int frag_base(int t, int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (KMAJOR) return (t * 32 + l31) * 64;             // the chunk is picked per k-step in frag()
+    // x-major: lane 4q+p of each 16-lane group addresses k-row q, operand rows 4p..4p+3 of the group's 16
+    const int g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    return xoff(8 * lh + q, t * 8 + 4 * g + p);
+  }
+  // 8 consecutive k (k = 16 s + 8 lh + j) of the lane's row, image `which`
+  __device__ __forceinline__ static bf16x8 frag(const char* __restrict__ lds, int base, int which, int row, int lh, int s) {
+    if (KMAJOR) {
+      const int chunk = (2 * s + lh) ^ ((row >> 2) & 3);
+      return *reinterpret_cast<const bf16x8*>(lds + which * IMG_BYTES + base + (chunk << 4));
+    }
+    // k-rows 16 s + 8 lh + q (+4): same swizzle class as the base row, so plain byte distances
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const char* p = lds + which * IMG_BYTES + base + s * 16 * (2 * ROWS);
+    union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+    u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+    u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * (2 * ROWS)));
+    return u.v;
   }
 };
 
@@ -211,6 +220,12 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   const long astep = AK ? (long)XBK : (long)XBK * g.lda;
   const long bstep = BKM ? (long)XBK : (long)XBK * g.ldb;
 
+  int fa[TM], fb[TN];      // per-lane fragment offsets
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[i] = TA::frag_base(wm * TM + i, lane);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb[j] = TB::frag_base(wn * TN + j, lane);
+
   float4 ra[TA::NV], rb[TB::NV];
   if (nkt > 0) {
     TA::load(ra, at, oa);
@@ -233,11 +248,11 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int w = 0; w < 3; ++w) af[i][w] = TA::frag(As, w, (wm * TM + i) * 32 + l31, lh, s);
+        for (int w = 0; w < 3; ++w) af[i][w] = TA::frag(As, fa[i], w, (wm * TM + i) * 32 + l31, lh, s);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int w = 0; w < 3; ++w) bf[j][w] = TB::frag(Bs, w, (wn * TN + j) * 32 + l31, lh, s);
+        for (int w = 0; w < 3; ++w) bf[j][w] = TB::frag(Bs, fb[j], w, (wn * TN + j) * 32 + l31, lh, s);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -77,10 +77,10 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   // exact-product split-bf16 path (fp32 in / out / accumulate, products via 3-way bf16 splitting on the
   // bf16 matrix pipe): every plain vector GEMM on a supported tile.  RPDE_SPLIT_BF16=0 forces the
   // native fp32 MFMA kernels.
-  static const bool split_on = [] { const char* e = getenv("RPDE_SPLIT_BF16"); return !(e && e[0] == '0'); }();
-  // (x-major operands need a transposing LDS staging that costs more than it saves: measured slower
-  //  than the fp32 kernel, so only NT problems go this way; RPDE_SPLIT_BF16=2 sends everything)
-  static const bool split_all = [] { const char* e = getenv("RPDE_SPLIT_BF16"); return e && e[0] == '2'; }();
+  // RPDE_SPLIT_BF16: 0 = native fp32 MFMA kernels only, 1 = split path for k-major x k-major problems only,
+  // default = every operand layout (x-major operands go through the transposing LDS read)
+  static const int split_mode = [] { const char* e = getenv("RPDE_SPLIT_BF16"); return e ? atoi(e) : 2; }();
+  const bool split_on = split_mode != 0, split_all = split_mode >= 2;
   // a pre-split B (rpde_split_weights) is k-major whatever the layout of the fp32 original
   const bool bimg = d.b_split && ak && d.sB1 == 0 && d.sB2 == 0 && g.kchunk % 32 == 0;
   if (split_on && vec && g.cvec && pro == 0 && d.K >= 32 && d.K % 32 == 0 && d.lda < (1L << 24) && d.ldb < (1L << 24) &&
