@@ -99,12 +99,15 @@ typedef struct {
    * rpde_split_weights for this B (same N, K).  Results are bit-identical with and without it; B must
    * still be valid (the native fp32 kernels use it when the split-bf16 path does not apply). */
   const void* b_split;
+  /* the same for an A operand shared by the whole batch (e.g. a DFT table): rpde_split_weights(A, a_kmajor,
+   * lda, M, K).  With it and an x-major B, K need not be a multiple of 32. */
+  const void* a_split;
 } rpde_gemm_desc;
 int rpde_gemm_f32(const rpde_gemm_desc* d, void* stream);
 
 /* Pre-split a weight operand for the split-bf16 GEMM path: w is [N,K] (kmajor=1, row stride ld) or [K,N]
- * (kmajor=0); out receives rpde_split_weights_bytes(N,K) bytes (0: K is not a multiple of 32, no such
- * path): three bf16 images hi/mid/lo with w = hi+mid+lo exactly, laid out as the kernel's LDS stages. */
+ * (kmajor=0); out receives rpde_split_weights_bytes(N,K) bytes: three bf16 images hi/mid/lo with
+ * w = hi+mid+lo exactly, laid out as the kernel's LDS stages (k zero-padded to a multiple of 32). */
 size_t rpde_split_weights_bytes(int N, int K);
 int rpde_split_weights(const float* w, int kmajor, int64_t ld, int N, int K, void* out, void* stream);
 

@@ -128,6 +128,17 @@ static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, i
     const int t1 = p->kp * p->ldn, t2 = n * p->kp;
     hipLaunchKernelGGL(k_real_analysis, dim3((t1 + 255) / 256), dim3(256), 0, st, p->fa, n, modes, p->kp, p->ldn, sf, planar);
     hipLaunchKernelGGL(k_real_synthesis, dim3((t2 + 255) / 256), dim3(256), 0, st, p->fs, n, modes, p->kp, si, planar);
+    if (!planar && p->ldn == n) {
+      const int m2 = 2 * p->kp;
+      RPDE_HIP(hipMalloc(&p->img[IMG_FA], split_bytes(m2, n)));
+      RPDE_HIP(hipMalloc(&p->img[IMG_FST], split_bytes(m2, n)));
+      RPDE_HIP(hipMalloc(&p->img[IMG_FS], split_bytes(n, m2)));
+      RPDE_HIP(hipMalloc(&p->img[IMG_FAT], split_bytes(n, m2)));
+      RPDE_TRY(split_weights(p->fa, 1, p->ldn, m2, n, p->img[IMG_FA], st));
+      RPDE_TRY(split_weights(p->fs, 0, m2, m2, n, p->img[IMG_FST], st));
+      RPDE_TRY(split_weights(p->fs, 1, m2, n, m2, p->img[IMG_FS], st));
+      RPDE_TRY(split_weights(p->fa, 0, p->ldn, n, m2, p->img[IMG_FAT], st));
+    }
   } else {
     if (bot < 0) bot = modes;
     RPDE_CHECK_ARG(modes <= n && bot <= n && modes >= 0 && bot >= 0 && modes + bot >= 1, "plan: rows (%d,%d) vs M %d", modes, bot, n);
@@ -185,6 +196,7 @@ int rpde_plan_destroy(rpde_plan* p) {
   if (!p) return RPDE_OK;
   if (p->fa) (void)hipFree(p->fa);
   if (p->fs) (void)hipFree(p->fs);
+  for (int i = 0; i < 4; ++i) if (p->img[i]) (void)hipFree(p->img[i]);
   delete p;
   return RPDE_OK;
 }

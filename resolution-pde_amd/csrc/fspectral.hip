@@ -41,8 +41,8 @@ static inline int split_for(long k_total, int tiles) {
 // spec[row][2kp][C] = table . field-line      (table = Fa, or Fs^T for the adjoint of synthesis)
 static int dft_analysis(const Axis& ax, const float* field, float* spec, int C, bool adjoint_of_synthesis, hipStream_t st) {
   rpde_gemm_desc d = gemm_desc();
-  if (!adjoint_of_synthesis) { d.A = ax.plan->fa; d.a_kmajor = 1; d.lda = ax.plan->ldn; }
-  else { d.A = ax.plan->fs; d.a_kmajor = 0; d.lda = 2L * ax.kp; }
+  if (!adjoint_of_synthesis) { d.A = ax.plan->fa; d.a_kmajor = 1; d.lda = ax.plan->ldn; d.a_split = ax.plan->img[IMG_FA]; }
+  else { d.A = ax.plan->fs; d.a_kmajor = 0; d.lda = 2L * ax.kp; d.a_split = ax.plan->img[IMG_FST]; }
   d.B = field; d.b_kmajor = 0; d.ldb = ax.ld;
   d.C = spec; d.ldc = C;
   d.M = 2 * ax.kp; d.N = C; d.K = ax.n;
@@ -56,8 +56,8 @@ static int dft_analysis(const Axis& ax, const float* field, float* spec, int C, 
 static int dft_synthesis(const Axis& ax, const float* spec, float* field, int C, bool adjoint_of_analysis, int accumulate,
                          hipStream_t st) {
   rpde_gemm_desc d = gemm_desc();
-  if (!adjoint_of_analysis) { d.A = ax.plan->fs; d.a_kmajor = 1; d.lda = 2L * ax.kp; }
-  else { d.A = ax.plan->fa; d.a_kmajor = 0; d.lda = ax.plan->ldn; }
+  if (!adjoint_of_analysis) { d.A = ax.plan->fs; d.a_kmajor = 1; d.lda = 2L * ax.kp; d.a_split = ax.plan->img[IMG_FS]; }
+  else { d.A = ax.plan->fa; d.a_kmajor = 0; d.lda = ax.plan->ldn; d.a_split = ax.plan->img[IMG_FAT]; }
   d.B = spec; d.b_kmajor = 0; d.ldb = C;
   d.C = field; d.ldc = ax.ld;
   d.M = ax.n; d.N = C; d.K = 2 * ax.kp;

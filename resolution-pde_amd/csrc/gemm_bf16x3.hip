@@ -94,6 +94,18 @@ struct XTile {
     for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const float4*>(tile + off[i]);
   }
 
+  // x-major only: last stage of a K that is not a multiple of 32 -- k-rows past `valid` re-read row valid-1
+  // (the other operand is a zero-padded pre-split image there, so they contribute exact zeros)
+  __device__ __forceinline__ static void load_tail(float4 (&r)[NV], const float* __restrict__ tile, const int (&off)[NV],
+                                                   int ld, int valid, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int rr, kk;
+      coords(tid, i, rr, kk);
+      r[i] = *reinterpret_cast<const float4*>(tile + off[i] - max(kk - (valid - 1), 0) * ld);
+    }
+  }
+
   // split into three bf16 images (hi, mid, lo at lds, lds + IMG, lds + 2*IMG)
   __device__ __forceinline__ static void store(char* __restrict__ lds, const float4 (&r)[NV], int tid) {
 #pragma unroll
@@ -155,11 +167,14 @@ __device__ __forceinline__ void bimg_store(char* __restrict__ lds, const u32x4 (
 // workgroup needs the same weight tile, so splitting it once per call instead of once per workgroup
 // removes half of the loop's vector instructions (MFMA and VALU issue serially on a SIMD, measured in
 // profiles/ubench/overlap.hip).
-template <int WM, int WN, int TM, int TN, bool AK, bool BKM, bool BIMG = false>
+// AIMG: the same for the A operand (the DFT tables of the spectral layers, split once per plan); with it
+// K may have a tail (the images are zero-padded to a multiple of 32) as long as B is x-major.
+template <int WM, int WN, int TM, int TN, bool AK, bool BKM, bool BIMG = false, bool AIMG = false>
 __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
-  using TA = XTile<BM, AK>;
+  static_assert(!(AIMG && BIMG), "one pre-split operand per product");
+  using TA = XTile<BM, AK || AIMG>;
   using TB = XTile<BN, BKM>;
   constexpr int SMEM_BYTES = 3 * (TA::IMG_BYTES + TB::IMG_BYTES);
   constexpr int SMEM_FLOATS = SMEM_BYTES / 4;
@@ -206,14 +221,18 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  constexpr int NBI = BIMG ? BN * 4 / NTHREADS : 1;       // 16-byte chunks per image per thread
+  constexpr int NBI = BIMG ? BN * 4 / NTHREADS : (AIMG ? BM * 4 / NTHREADS : 1);   // 16-byte chunks per image per thread
   static_assert(!BIMG || (BKM && NBI >= 1), "pre-split B is k-major");
+  constexpr bool IMG = AIMG || BIMG;
   int oa[TA::NV], ob[TB::NV];
-  TA::prep(oa, g.lda, m0, g.M, tid);
+  if (!AIMG) TA::prep(oa, g.lda, m0, g.M, tid);
   if (!BIMG) TB::prep(ob, g.ldb, n0, g.N, tid);
-  const char* __restrict__ bimg = g.Bimg + ((long)(kbeg / XBK) * 3 * g.npad + n0) * 64 + tid * 16;
+  // the pre-split operand (either one): rows r0.. of every stage are one contiguous block per image
+  const char* __restrict__ bimg = g.Bimg + ((long)(kbeg / XBK) * 3 * g.npad + (AIMG ? m0 : n0)) * 64 + tid * 16;
   const long bimg_step = 3L * g.npad * 64;
   u32x4 rbi[3 * NBI];
+  // K tail (AIMG with an x-major B only): number of valid k-rows of the last stage, 0 = full
+  const int tail = (AIMG && !BKM) ? ((kend - kbeg) & (XBK - 1)) : 0;
   // uniform tile origins, advanced by one stage per iteration
   const float* __restrict__ at = AK ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
   const float* __restrict__ bt = BKM ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
@@ -228,19 +247,25 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
 
   float4 ra[TA::NV], rb[TB::NV];
   if (nkt > 0) {
-    TA::load(ra, at, oa);
-    if (BIMG) bimg_load<NBI>(rbi, bimg, (long)g.npad * 64); else TB::load(rb, bt, ob);
+    if (!AIMG) TA::load(ra, at, oa);
+    if (IMG) bimg_load<NBI>(rbi, bimg, (long)g.npad * 64);
+    if (!BIMG) {
+      if (tail && nkt == 1) TB::load_tail(rb, bt, ob, (int)g.ldb, tail, tid); else TB::load(rb, bt, ob);
+    }
   }
   // (a second register set fetching two stages ahead was measured slower here: the extra 32 VGPRs cost
   //  a resident wave, and three workgroups per CU already cover the load latency)
   for (int kt = 0; kt < nkt; ++kt) {
-    TA::store(As, ra, tid);
+    if (AIMG) bimg_store<NBI>(As + tid * 16, rbi, TA::IMG_BYTES); else TA::store(As, ra, tid);
     if (BIMG) bimg_store<NBI>(Bs + tid * 16, rbi, TB::IMG_BYTES); else TB::store(Bs, rb, tid);
     __syncthreads();
     if (kt + 1 < nkt) {
       at += astep; bt += bstep; bimg += bimg_step;
-      TA::load(ra, at, oa);
-      if (BIMG) bimg_load<NBI>(rbi, bimg, (long)g.npad * 64); else TB::load(rb, bt, ob);
+      if (!AIMG) TA::load(ra, at, oa);
+      if (IMG) bimg_load<NBI>(rbi, bimg, (long)g.npad * 64);
+      if (!BIMG) {
+        if (tail && kt + 2 == nkt) TB::load_tail(rb, bt, ob, (int)g.ldb, tail, tid); else TB::load(rb, bt, ob);
+      }
     }
 #pragma unroll
     for (int s = 0; s < XBK / 16; ++s) {
@@ -359,7 +384,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
 
 template <int WM, int WN, int TM, int TN>
 static void launch_x3_layout(const GemmK& g, bool ak, bool bk, dim3 grid, hipStream_t st) {
-  if (ak && bk && g.Bimg) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(NTHREADS), 0, st, g);
+  if (g.a_img && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true, false, true>), grid, dim3(NTHREADS), 0, st, g);
+  else if (g.a_img) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, false, false, true>), grid, dim3(NTHREADS), 0, st, g);
+  else if (ak && bk && g.Bimg) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(NTHREADS), 0, st, g);
   else if (ak && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true>), grid, dim3(NTHREADS), 0, st, g);
   else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, false>), grid, dim3(NTHREADS), 0, st, g);
   else if (!ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, false>), grid, dim3(NTHREADS), 0, st, g);
@@ -371,13 +398,14 @@ static void launch_x3_layout(const GemmK& g, bool ak, bool bk, dim3 grid, hipStr
 __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, int kmajor, long ld, int N, int K,
                                                        int npad, char* __restrict__ out) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  const int kchunks = K / 8;
+  const int kchunks = ((K + XBK - 1) / XBK) * (XBK / 8);
   if (t >= (long)npad * kchunks) return;
   const int n = (int)(t % npad), kc = (int)(t / npad);     // consecutive threads: consecutive rows
   const int k0 = kc * 8;
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = n < N ? (kmajor ? w[(long)n * ld + k0 + j] : w[(long)(k0 + j) * ld + n]) : 0.f;
+  for (int j = 0; j < 8; ++j)
+    v[j] = (n < N && k0 + j < K) ? (kmajor ? w[(long)n * ld + k0 + j] : w[(long)(k0 + j) * ld + n]) : 0.f;
   unsigned h[4], m[4], l[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
@@ -389,25 +417,26 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
 }
 
 int split_npad(int N) { return ((N + 127) / 128) * 128; }
-size_t split_bytes(int N, int K) { return (size_t)(K / XBK) * 3 * split_npad(N) * 64; }
+size_t split_bytes(int N, int K) { return (size_t)((K + XBK - 1) / XBK) * 3 * split_npad(N) * 64; }
 
 int split_weights(const float* w, int kmajor, long ld, int N, int K, void* out, hipStream_t st) {
-  RPDE_CHECK_ARG(w && out && N > 0 && K >= XBK && K % XBK == 0, "split_weights: K must be a positive multiple of 32 (got N=%d K=%d)", N, K);
+  RPDE_CHECK_ARG(w && out && N > 0 && K > 0, "split_weights: bad arguments (N=%d K=%d)", N, K);
   RPDE_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0, "split_weights: output must be 16-byte aligned");
   const int npad = split_npad(N);
-  const long threads = (long)npad * (K / 8);
+  const long threads = (long)npad * ((K + XBK - 1) / XBK) * (XBK / 8);
   hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, w, kmajor, ld, N, K, npad,
                      static_cast<char*>(out));
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;
 }
 
-bool bf16x3_supports(int bm, int bn) { return (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128); }
+bool bf16x3_supports(int bm, int bn) { return (bm == 128 || bm == 64) && (bn == 128 || bn == 64); }
 
 int launch_bf16x3(const GemmK& g, int bm, int bn, bool ak, bool bk, dim3 grid, hipStream_t st) {
   if (bm == 128 && bn == 128) launch_x3_layout<2, 2, 2, 2>(g, ak, bk, grid, st);
   else if (bm == 128 && bn == 64) launch_x3_layout<4, 1, 1, 2>(g, ak, bk, grid, st);
   else if (bm == 64 && bn == 128) launch_x3_layout<1, 4, 2, 1>(g, ak, bk, grid, st);
+  else if (bm == 64 && bn == 64) launch_x3_layout<2, 2, 1, 1>(g, ak, bk, grid, st);
   else { set_error("bf16x3: unsupported tile %dx%d", bm, bn); return RPDE_ERR_ARG; }
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;
@@ -415,7 +444,7 @@ int launch_bf16x3(const GemmK& g, int bm, int bn, bool ak, bool bk, dim3 grid, h
 
 }  // namespace rpde
 
-extern "C" size_t rpde_split_weights_bytes(int N, int K) { return K % rpde::XBK == 0 ? rpde::split_bytes(N, K) : 0; }
+extern "C" size_t rpde_split_weights_bytes(int N, int K) { return (N > 0 && K > 0) ? rpde::split_bytes(N, K) : 0; }
 extern "C" int rpde_split_weights(const float* w, int kmajor, int64_t ld, int N, int K, void* out, void* stream) {
   return rpde::split_weights(w, kmajor, (long)ld, N, K, out, rpde::as_stream(stream));
 }

@@ -68,7 +68,7 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
            (!(d.bias && d.bias_mode == 1) || al16(d.bias)) && (!(g.drop.on() && (d.drop_where & 4)) || d.drop_ld % 4 == 0);
   g.colsum = d.colsum;
   g.aux_out = d.aux_out;
-  g.Bimg = nullptr; g.npad = 0;
+  g.Bimg = nullptr; g.npad = 0; g.a_img = 0;
   RPDE_CHECK_ARG(!d.aux_out || d.write_act, "gemm: aux_out needs write_act");
   if (d.aux_out) g.cvec = g.cvec && al16(d.aux_out);
   RPDE_CHECK_ARG(!d.colsum || (g.cvec && BMc == 128 && d.batch == 1 && d.ksplit == 1),
@@ -81,15 +81,22 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   // default = every operand layout (x-major operands go through the transposing LDS read)
   static const int split_mode = [] { const char* e = getenv("RPDE_SPLIT_BF16"); return e ? atoi(e) : 2; }();
   const bool split_on = split_mode != 0, split_all = split_mode >= 2;
-  // a pre-split B (rpde_split_weights) is k-major whatever the layout of the fp32 original
-  const bool bimg = d.b_split && ak && d.sB1 == 0 && d.sB2 == 0 && g.kchunk % 32 == 0;
-  if (split_on && vec && g.cvec && pro == 0 && d.K >= 32 && d.K % 32 == 0 && d.lda < (1L << 24) && d.ldb < (1L << 24) &&
-      ((ak && (bk || bimg)) || split_all) && bf16x3_supports(BMc, BNc)) {
+  // a pre-split operand (rpde_split_weights) is k-major whatever the layout of the fp32 original, and
+  // zero-padded in k: with a pre-split A and an x-major B any K works
+  const bool bimg = d.b_split && ak && d.sB1 == 0 && d.sB2 == 0 && g.kchunk % 32 == 0 && d.K % 32 == 0;
+  const bool aimg = !bimg && d.a_split && d.sA1 == 0 && d.sA2 == 0 && g.kchunk % 32 == 0 && (d.K % 32 == 0 || (!bk && d.ksplit == 1));
+  const bool k_ok = d.K >= 32 && d.K % 32 == 0;
+  if (split_on && vec && g.cvec && pro == 0 && (k_ok || (aimg && d.K >= 1)) && d.lda < (1L << 24) && d.ldb < (1L << 24) &&
+      (((ak || aimg) && (bk || bimg)) || split_all) && bf16x3_supports(BMc, BNc)) {
     if (bimg) {
       g.Bimg = static_cast<const char*>(d.b_split);
       g.npad = split_npad(d.N);
+    } else if (aimg) {
+      g.Bimg = static_cast<const char*>(d.a_split);
+      g.npad = split_npad(d.M);
+      g.a_img = 1;
     }
-    return launch_bf16x3(g, BMc, BNc, ak, bk || bimg, grid, st);
+    return launch_bf16x3(g, BMc, BNc, ak || aimg, bk || bimg, grid, st);
   }
 
   if (ak && bk) return launch_nt(g, BMc, BNc, pro, vec, grid, st);

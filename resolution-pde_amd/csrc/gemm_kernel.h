@@ -58,8 +58,9 @@ struct GemmK {
   int cvec;          // C / aux / bias allow 16-byte row accesses: LDS-staged epilogue
   float* colsum;     // optional [mtiles][N] per-M-tile column sums of the stored C
   float* aux_out;    // optional act'(u)*dropscale beside C = act(u)
-  const char* Bimg;  // optional pre-split B (split_weights), split-bf16 NT path only
+  const char* Bimg;  // optional pre-split operand (split_weights): B, or A when a_img is set
   int npad;          // rows per image of Bimg
+  int a_img;
 };
 
 template <int ROWS, int BK, bool KMAJOR, bool VEC, bool PRO>

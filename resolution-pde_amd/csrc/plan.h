@@ -11,10 +11,14 @@ struct rpde_plan {
   int ldn;      // leading dim of fa: real: n rounded up to 4;  complex: 2n
   float* fa;    // real: [2kp, ldn] analysis;     complex: [2R, 2n]
   float* fs;    // real: [n, 2kp] synthesis;      complex: [2n, 2R]
+  // real, interleaved plans: the tables pre-split for the split-bf16 GEMM (gemm_bf16x3.hip), as A operands:
+  // [IMG_FA] Fa (2kp x n), [IMG_FST] Fs^T (2kp x n), [IMG_FS] Fs (n x 2kp), [IMG_FAT] Fa^T (n x 2kp)
+  void* img[4];
 };
 
 namespace rpde {
 enum { PLAN_REAL = 0, PLAN_CPLX = 1 };
+enum { IMG_FA = 0, IMG_FST = 1, IMG_FS = 2, IMG_FAT = 3 };
 // cached per (device, n, modes, norm, planar, kind); never freed
 // PLAN_CPLX: `modes` = rows kept from the top of the spectrum, `bot` = rows kept from the bottom (-1: same)
 int get_plan(const rpde_plan** out, int n, int modes, int norm, int planar, int kind, hipStream_t st, int bot = -1);

@@ -154,6 +154,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 int launch_gemm(const rpde_gemm_desc& d, hipStream_t stream);
+// pre-split operands of the split-bf16 GEMM (gemm_bf16x3.hip)
+int split_npad(int N);
+size_t split_bytes(int N, int K);
+int split_weights(const float* w, int kmajor, long ld, int N, int K, void* out, hipStream_t st);
 
 inline rpde_gemm_desc gemm_desc() {
   rpde_gemm_desc d;

@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64),
         ("write_act", C.c_int), ("drop_where", C.c_int),
-        ("colsum", C.c_void_p), ("aux_out", C.c_void_p), ("b_split", C.c_void_p),
+        ("colsum", C.c_void_p), ("aux_out", C.c_void_p), ("b_split", C.c_void_p), ("a_split", C.c_void_p),
     ]
 
 

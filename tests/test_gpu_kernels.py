@@ -267,6 +267,37 @@ def test_presplit_weight_operand_is_bit_identical(gpu_device, M, N, K, b_k):
         assert not rec[N:].any()
 
 
+@pytest.mark.parametrize("M,N,K,a_k,acc", [(40, 64, 256, 1, False), (40, 64, 256, 0, False), (256, 64, 40, 1, True),
+                                           (256, 64, 40, 0, False), (24, 32, 100, 1, False), (512, 128, 72, 1, True)])
+def test_presplit_table_operand_with_k_tail(gpu_device, M, N, K, a_k, acc):
+    """rpde_gemm_desc.a_split: a batch-shared A (a DFT table) pre-split once; B x-major per batch entry
+    (a channels-last field line).  K need not be a multiple of 32 (the images are zero-padded)."""
+    from rpde import _lib
+    lib = _lib.load()
+    dev = gpu_device
+    batch = 7
+    g = torch.Generator(device="cpu").manual_seed(M * 3 + N + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(batch, K, N, generator=g)
+    C0 = torch.randn(batch, M, N, generator=g)
+    Ad = (A if a_k else A.t()).contiguous().to(dev)
+    Bd, Cd = Bm.to(dev), C0.clone().to(dev)
+    img = torch.empty(lib.rpde_split_weights_bytes(M, K), dtype=torch.uint8, device=dev)
+    _lib.check(lib.rpde_split_weights(Ad.data_ptr(), a_k, K if a_k else M, M, K, img.data_ptr(), _lib.stream_ptr()), "split")
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = M, N, K, a_k, 0
+    d.lda, d.ldb, d.ldc = (K if a_k else M), N, N
+    d.batch, d.zdiv, d.ksplit, d.alpha = batch, 1, 1, 1.0
+    d.sB1, d.sC1 = K * N, M * N
+    d.accumulate = int(acc)
+    d.a_split = img.data_ptr()
+    _lib.check(lib.rpde_gemm_f32(C.byref(d), _lib.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    ref = A.double()[None] @ Bm.double() + (C0.double() if acc else 0)
+    assert float((Cd.cpu().double() - ref).norm() / ref.norm()) < GEMM_TOL
+
+
 def test_native_fp32_mfma_path_stays_green(gpu_device):
     """The default dispatch sends NT problems to the split-bf16 kernel; one child process re-runs the
     kernel and golden parity tests with RPDE_SPLIT_BF16=0 so the native fp32-MFMA kernels stay covered."""
