@@ -102,6 +102,9 @@ typedef struct {
   /* the same for an A operand shared by the whole batch (e.g. a DFT table): rpde_split_weights(A, a_kmajor,
    * lda, M, K).  With it and an x-major B, K need not be a multiple of 32. */
   const void* a_split;
+  /* with accumulate: add this tensor (same layout and strides as C) instead of the old contents of C,
+   * i.e. C = alpha*A.B + acc_src -- sums a skip-connection gradient without a separate pass */
+  const float* acc_src;
 } rpde_gemm_desc;
 int rpde_gemm_f32(const rpde_gemm_desc* d, void* stream);
 
@@ -120,8 +123,10 @@ size_t rpde_fspectral1d_spec_elems(int B, int n, int C, int K);
 int rpde_fspectral1d_fwd(const float* x, const float* w, float* out, float* spec_in,
                          int B, int n, int C, int K, int mode, int norm,
                          void* ws, size_t ws_bytes, void* stream);
+/* grad_skip (nullable, shaped like x): added into grad_x by the last GEMM's epilogue -- the gradient
+ * arriving through a skip connection around the layer (x + FF(spectral(x))) costs no extra pass */
 int rpde_fspectral1d_bwd(const float* grad_out, const float* spec_in, const float* w,
-                         float* grad_x, float* grad_w,
+                         float* grad_x, float* grad_w, const float* grad_skip,
                          int B, int n, int C, int K, int mode, int norm,
                          void* ws, size_t ws_bytes, void* stream);
 
@@ -136,7 +141,7 @@ int rpde_fspectral2d_fwd(const float* x, const float* w_y, const float* w_x, flo
                          void* ws, size_t ws_bytes, void* stream);
 int rpde_fspectral2d_bwd(const float* grad_out, const float* spec_y, const float* spec_x,
                          const float* w_y, const float* w_x,
-                         float* grad_x, float* grad_wy, float* grad_wx,
+                         float* grad_x, float* grad_wy, float* grad_wx, const float* grad_skip,
                          int B, int M, int N, int C, int K, int mode,
                          void* ws, size_t ws_bytes, void* stream);
 

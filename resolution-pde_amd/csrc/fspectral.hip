@@ -53,8 +53,9 @@ static int dft_analysis(const Axis& ax, const float* field, float* spec, int C, 
 }
 
 // field-line (+)= table . spec[row]           (table = Fs, or Fa^T for the adjoint of analysis)
+// accumulate: 0 overwrite, 1 add to field, 2 field = result + acc_src (a tensor laid out like field)
 static int dft_synthesis(const Axis& ax, const float* spec, float* field, int C, bool adjoint_of_analysis, int accumulate,
-                         hipStream_t st) {
+                         hipStream_t st, const float* acc_src = nullptr) {
   rpde_gemm_desc d = gemm_desc();
   if (!adjoint_of_analysis) { d.A = ax.plan->fs; d.a_kmajor = 1; d.lda = 2L * ax.kp; d.a_split = ax.plan->img[IMG_FS]; }
   else { d.A = ax.plan->fa; d.a_kmajor = 0; d.lda = ax.plan->ldn; d.a_split = ax.plan->img[IMG_FAT]; }
@@ -64,7 +65,8 @@ static int dft_synthesis(const Axis& ax, const float* spec, float* field, int C,
   d.batch = ax.rows; d.zdiv = ax.zdiv;
   d.sB1 = (long)ax.zdiv * 2 * ax.kp * C; d.sB2 = 2L * ax.kp * C;
   d.sC1 = ax.s1; d.sC2 = ax.s2;
-  d.accumulate = accumulate;
+  d.accumulate = accumulate ? 1 : 0;
+  d.acc_src = accumulate == 2 ? acc_src : nullptr;
   return launch_gemm(d, st);
 }
 
@@ -138,7 +140,7 @@ static int axis_fwd(const Axis& ax, const float* x, const float* w, int K, float
 
 // backward of one axis: g -> gx (+)=, gw
 static int axis_bwd(const Axis& ax, const float* g, const float* spec_in, const float* w, int K, float* gx, float* gw, int C,
-                    int mode, int accumulate, Arena& ar, hipStream_t st) {
+                    int mode, int accumulate, Arena& ar, hipStream_t st, const float* skip = nullptr) {
   float* gspec = ar.take(spec_floats(ax, C));
   if (!ar.ok()) { set_error("fspectral: workspace too small"); return RPDE_ERR_WORKSPACE; }
   RPDE_TRY(dft_analysis(ax, g, gspec, C, true, st));
@@ -162,7 +164,7 @@ static int axis_bwd(const Axis& ax, const float* g, const float* spec_in, const 
   } else if (gw) {
     RPDE_HIP(hipMemsetAsync(gw, 0, sizeof(float) * 2 * (size_t)C * C * K, st));
   }
-  if (gx) RPDE_TRY(dft_synthesis(ax, dspec, gx, C, true, accumulate, st));
+  if (gx) RPDE_TRY(dft_synthesis(ax, dspec, gx, C, true, (!accumulate && skip) ? 2 : accumulate, st, skip));
   return RPDE_OK;
 }
 
@@ -194,15 +196,16 @@ int rpde_fspectral1d_fwd(const float* x, const float* w, float* out, float* spec
   return axis_fwd(ax, x, w, K, out, spec_in, C, mode, 0, ar, st);
 }
 
-int rpde_fspectral1d_bwd(const float* grad_out, const float* spec_in, const float* w, float* grad_x, float* grad_w, int B,
-                         int n, int C, int K, int mode, int norm, void* ws, size_t ws_bytes, void* stream) {
+int rpde_fspectral1d_bwd(const float* grad_out, const float* spec_in, const float* w, float* grad_x, float* grad_w,
+                         const float* grad_skip, int B, int n, int C, int K, int mode, int norm, void* ws, size_t ws_bytes,
+                         void* stream) {
   RPDE_CHECK_ARG(grad_out && spec_in && B > 0 && n > 0 && C > 0 && K > 0, "fspectral1d_bwd: bad arguments");
   RPDE_CHECK_ARG(mode == RPDE_MODE_LOWPASS || w, "fspectral1d_bwd: null weight");
   hipStream_t st = as_stream(stream);
   Axis ax;
   RPDE_TRY(make_axis(ax, n, K, norm, B, 1, (long)n * C, 0, C, st));
   Arena ar(ws, ws_bytes);
-  return axis_bwd(ax, grad_out, spec_in, w, K, grad_x, grad_w, C, mode, 0, ar, st);
+  return axis_bwd(ax, grad_out, spec_in, w, K, grad_x, grad_w, C, mode, 0, ar, st, grad_skip);
 }
 
 // ------------------------------- 2-D ---------------------------------------
@@ -239,8 +242,8 @@ int rpde_fspectral2d_fwd(const float* x, const float* w_y, const float* w_x, flo
 }
 
 int rpde_fspectral2d_bwd(const float* grad_out, const float* spec_y, const float* spec_x, const float* w_y, const float* w_x,
-                         float* grad_x, float* grad_wy, float* grad_wx, int B, int M, int N, int C, int K, int mode, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         float* grad_x, float* grad_wy, float* grad_wx, const float* grad_skip, int B, int M, int N, int C,
+                         int K, int mode, void* ws, size_t ws_bytes, void* stream) {
   RPDE_CHECK_ARG(grad_out && spec_y && spec_x && B > 0 && M > 0 && N > 0 && C > 0 && K > 0, "fspectral2d_bwd: bad arguments");
   RPDE_CHECK_ARG(mode == RPDE_MODE_LOWPASS || (w_y && w_x), "fspectral2d_bwd: null weight");
   hipStream_t st = as_stream(stream);
@@ -249,7 +252,7 @@ int rpde_fspectral2d_bwd(const float* grad_out, const float* spec_y, const float
   RPDE_TRY(make_axis(ax, M, K, RPDE_NORM_ORTHO, B * N, N, (long)M * N * C, C, (long)N * C, st));
   {
     Arena ar(ws, ws_bytes);
-    RPDE_TRY(axis_bwd(ax, grad_out, spec_x, w_x, K, grad_x, grad_wx, C, mode, 0, ar, st));
+    RPDE_TRY(axis_bwd(ax, grad_out, spec_x, w_x, K, grad_x, grad_wx, C, mode, 0, ar, st, grad_skip));
   }
   Arena ar(ws, ws_bytes);
   return axis_bwd(ay, grad_out, spec_y, w_y, K, grad_x, grad_wy, C, mode, 1, ar, st);

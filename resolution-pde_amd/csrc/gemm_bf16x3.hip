@@ -309,6 +309,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   float4 bn4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g.bias_mode == 1 && gn < g.N) bn4 = *reinterpret_cast<const float4*>(g.bias + gn);
   const float* __restrict__ aux = g.aux ? g.aux + coff : nullptr;
+  const bool plain = g.bias_mode != 2 && !g.accumulate;
+  const bool fast_hd = plain && g.write_act == RPDE_ACT_GELU && g.aux_out && !g.epi_dact;
+  const bool fast_mul = plain && g.epi_dact == RPDE_EPI_MULAUX && !g.write_act;
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
     if (e > 0) __syncthreads();
@@ -326,46 +329,89 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
     }
     __syncthreads();
     if (gn < g.N) {
-#pragma unroll 4
-      for (int it = 0; it < NV4; ++it) {
-        const int row = row0 + it * RSTEP;
-        const int gm = m0 + e * SLAB + row;
-        if (gm >= g.M) break;
-        float4 v = *reinterpret_cast<const float4*>(cs + row * BN + c4);
-        v.x = fmaf(v.x, g.alpha, bn4.x); v.y = fmaf(v.y, g.alpha, bn4.y);
-        v.z = fmaf(v.z, g.alpha, bn4.z); v.w = fmaf(v.w, g.alpha, bn4.w);
-        if (g.bias_mode == 2) { const float bm = g.bias[gm]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
-        if (g.epi_dact == RPDE_EPI_MULAUX) {
-          const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
-          v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
-        } else if (g.epi_dact) {
+      // the mode is uniform over the launch: pick the row loop once, not per element
+      if (fast_hd) {
+        // C = gelu(u), aux_out = gelu'(u) * dropscale, u = dropout(alpha*acc + bias): packed fp32 math
+        float* __restrict__ dout = g.aux_out + coff;
+#pragma unroll 2
+        for (int it = 0; it < NV4; ++it) {
+          const int row = row0 + it * RSTEP;
+          const int gm = m0 + e * SLAB + row;
+          if (gm >= g.M) break;
+          const float4 t = *reinterpret_cast<const float4*>(cs + row * BN + c4);
           float s[4] = {1.f, 1.f, 1.f, 1.f};
           if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+          const f32x2 s01 = {s[0], s[1]}, s23 = {s[2], s[3]};
+          const f32x2 al = (f32x2)(g.alpha);
+          const f32x2 u01 = __builtin_elementwise_fma((f32x2){t.x, t.y}, al, (f32x2){bn4.x, bn4.y}) * s01;
+          const f32x2 u23 = __builtin_elementwise_fma((f32x2){t.z, t.w}, al, (f32x2){bn4.z, bn4.w}) * s23;
+          f32x2 h01, d01, h23, d23;
+          gelu_both2(u01, h01, d01);
+          gelu_both2(u23, h23, d23);
+          d01 *= s01; d23 *= s23;
+          *reinterpret_cast<float4*>(dout + (long)gm * g.ldc + gn) = make_float4(d01.x, d01.y, d23.x, d23.y);
+          *reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn) = make_float4(h01.x, h01.y, h23.x, h23.y);
+          csum.x += h01.x; csum.y += h01.y; csum.z += h23.x; csum.w += h23.y;
+        }
+      } else if (fast_mul) {
+        // C = (alpha*acc + bias) * aux: backward-data through the stored derivative
+#pragma unroll 4
+        for (int it = 0; it < NV4; ++it) {
+          const int row = row0 + it * RSTEP;
+          const int gm = m0 + e * SLAB + row;
+          if (gm >= g.M) break;
+          float4 v = *reinterpret_cast<const float4*>(cs + row * BN + c4);
           const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
-          v.x *= dact_f(g.epi_dact, a.x * s[0]) * s[0];
-          v.y *= dact_f(g.epi_dact, a.y * s[1]) * s[1];
-          v.z *= dact_f(g.epi_dact, a.z * s[2]) * s[2];
-          v.w *= dact_f(g.epi_dact, a.w * s[3]) * s[3];
+          v.x = fmaf(v.x, g.alpha, bn4.x) * a.x; v.y = fmaf(v.y, g.alpha, bn4.y) * a.y;
+          v.z = fmaf(v.z, g.alpha, bn4.z) * a.z; v.w = fmaf(v.w, g.alpha, bn4.w) * a.w;
+          *reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn) = v;
+          csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
         }
-        float4* cp = reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn);
-        if (g.accumulate) { const float4 o = *cp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        if (g.write_act) {
-          float s[4] = {1.f, 1.f, 1.f, 1.f};
-          if (drop_e && !g.epi_dact) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
-          v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
-          if (g.aux_out) {
-            float4 dv;
-            act_both(g.write_act, v.x, v.x, dv.x); act_both(g.write_act, v.y, v.y, dv.y);
-            act_both(g.write_act, v.z, v.z, dv.z); act_both(g.write_act, v.w, v.w, dv.w);
-            dv.x *= s[0]; dv.y *= s[1]; dv.z *= s[2]; dv.w *= s[3];
-            *reinterpret_cast<float4*>(g.aux_out + coff + (long)gm * g.ldc + gn) = dv;
-          } else {
-            v.x = act_f(g.write_act, v.x); v.y = act_f(g.write_act, v.y);
-            v.z = act_f(g.write_act, v.z); v.w = act_f(g.write_act, v.w);
+      } else {
+#pragma unroll 4
+        for (int it = 0; it < NV4; ++it) {
+          const int row = row0 + it * RSTEP;
+          const int gm = m0 + e * SLAB + row;
+          if (gm >= g.M) break;
+          float4 v = *reinterpret_cast<const float4*>(cs + row * BN + c4);
+          v.x = fmaf(v.x, g.alpha, bn4.x); v.y = fmaf(v.y, g.alpha, bn4.y);
+          v.z = fmaf(v.z, g.alpha, bn4.z); v.w = fmaf(v.w, g.alpha, bn4.w);
+          if (g.bias_mode == 2) { const float bm = g.bias[gm]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+          if (g.epi_dact == RPDE_EPI_MULAUX) {
+            const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
+            v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
+          } else if (g.epi_dact) {
+            float s[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+            const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
+            v.x *= dact_f(g.epi_dact, a.x * s[0]) * s[0];
+            v.y *= dact_f(g.epi_dact, a.y * s[1]) * s[1];
+            v.z *= dact_f(g.epi_dact, a.z * s[2]) * s[2];
+            v.w *= dact_f(g.epi_dact, a.w * s[3]) * s[3];
           }
+          float4* cp = reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn);
+          if (g.accumulate) {
+            const float4 o = g.acc_src ? *reinterpret_cast<const float4*>(g.acc_src + coff + (long)gm * g.ldc + gn) : *cp;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          if (g.write_act) {
+            float s[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop_e && !g.epi_dact) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+            v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
+            if (g.aux_out) {
+              float4 dv;
+              act_both(g.write_act, v.x, v.x, dv.x); act_both(g.write_act, v.y, v.y, dv.y);
+              act_both(g.write_act, v.z, v.z, dv.z); act_both(g.write_act, v.w, v.w, dv.w);
+              dv.x *= s[0]; dv.y *= s[1]; dv.z *= s[2]; dv.w *= s[3];
+              *reinterpret_cast<float4*>(g.aux_out + coff + (long)gm * g.ldc + gn) = dv;
+            } else {
+              v.x = act_f(g.write_act, v.x); v.y = act_f(g.write_act, v.y);
+              v.z = act_f(g.write_act, v.z); v.w = act_f(g.write_act, v.w);
+            }
+          }
+          *cp = v;
+          csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
         }
-        *cp = v;
-        csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
       }
     }
   }

@@ -69,6 +69,8 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   g.colsum = d.colsum;
   g.aux_out = d.aux_out;
   g.Bimg = nullptr; g.npad = 0; g.a_img = 0;
+  g.acc_src = d.accumulate ? d.acc_src : nullptr;
+  if (g.acc_src) g.cvec = g.cvec && al16(g.acc_src);
   RPDE_CHECK_ARG(!d.aux_out || d.write_act, "gemm: aux_out needs write_act");
   if (d.aux_out) g.cvec = g.cvec && al16(d.aux_out);
   RPDE_CHECK_ARG(!d.colsum || (g.cvec && BMc == 128 && d.batch == 1 && d.ksplit == 1),

@@ -61,6 +61,7 @@ struct GemmK {
   const char* Bimg;  // optional pre-split operand (split_weights): B, or A when a_img is set
   int npad;          // rows per image of Bimg
   int a_img;
+  const float* acc_src;   // accumulate reads this tensor (laid out like C) instead of C itself
 };
 
 template <int ROWS, int BK, bool KMAJOR, bool VEC, bool PRO>
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
   constexpr int PA_NV4 = PA_SLAB * BN / 4 / NTHREADS;
   float4 pre[PREAUX ? PA_EP * PA_NV4 : 1];
   if constexpr (PREAUX) {
-    const float* __restrict__ src = g.accumulate ? C : g.aux + coff;
+    const float* __restrict__ src = g.accumulate ? (g.acc_src ? g.acc_src + coff : C) : g.aux + coff;
     const long lds_ = g.accumulate ? g.ldc : g.ldaux;
     const int c4p = (tid % PA_VPR) * 4, row0p = tid / PA_VPR;
     const int gnp = min(n0 + c4p, g.N - 4);
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
           if (g.accumulate) {
             float4 o;
             if constexpr (PREAUX) o = pre[e * NV4 + it];
-            else o = *cp;
+            else o = g.acc_src ? *reinterpret_cast<const float4*>(g.acc_src + coff + (long)gm * g.ldc + gn) : *cp;
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
           }
           if (g.write_act) {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
             const float u = ab[dm * g.ldaux] * s;
             v = v * dact_f(g.epi_dact, u) * s;
           }
-          if (g.accumulate) v += cb[dm * ldc];
+          if (g.accumulate) v += g.acc_src ? g.acc_src[coff + (long)(mb + dm) * ldc + n] : cb[dm * ldc];
           if (g.write_act) {
             float s = 1.f;
             if (drop_e && !g.epi_dact) s = drop_scale1(g.drop, idb + (uint64_t)(dm * g.drop_ld));

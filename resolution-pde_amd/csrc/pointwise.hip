@@ -17,8 +17,17 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + tx;
   float acc = 0.f;
-  if (i < n)
-    for (int s = ty; s < S; s += 4) acc += slabs[(long)s * stride + i];
+  if (i < n) {
+    // eight loads in flight per lane: with few outputs and many slabs this loop is pure load latency
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = ty;
+    for (; s + 28 < S; s += 32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += slabs[(long)(s + 4 * j) * stride + i];
+    }
+    for (; s < S; s += 4) a[0] += slabs[(long)s * stride + i];
+    acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && i < n) {

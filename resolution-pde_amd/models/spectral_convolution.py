@@ -80,12 +80,16 @@ class FSpectralConv1d(nn.Module):
         self.activation = activation
         self.act = act_registry[activation]
 
-    def forward_fourier(self, x):
-        return ops.fspectral1d(x, self.fourier_weight[0], self.n_modes, self.mode, self.fft_norm)
+    def forward_fourier(self, x, with_skip=False):
+        return ops.fspectral1d(x, self.fourier_weight[0], self.n_modes, self.mode, self.fft_norm, with_skip=with_skip)
 
     def forward(self, x, batch_dt=None, residual=None):
         if self.mode != "no-fourier":
-            x = self.forward_fourier(x)
+            if residual is x and torch.is_grad_enabled() and x.requires_grad:
+                # skip connection around this layer: its gradient is summed inside the spectral backward
+                x, residual = self.forward_fourier(x, with_skip=True)
+            else:
+                x = self.forward_fourier(x)
         return self.backcast_ff(x, residual=residual, post_act=self.activation), None
 
 
@@ -109,12 +113,16 @@ class FSpectralConv2d(nn.Module):
                 d_model, factor, n_layers=n_ff_layers, ff_weight_norm=ff_weight_norm, layer_norm=layer_norm,
                 dropout=dropout)
 
-    def forward_fourier(self, x):
-        return ops.fspectral2d(x, self.fourier_weight[0], self.fourier_weight[1], self.n_modes, self.mode)
+    def forward_fourier(self, x, with_skip=False):
+        return ops.fspectral2d(x, self.fourier_weight[0], self.fourier_weight[1], self.n_modes, self.mode,
+                               with_skip=with_skip)
 
     def forward(self, x, batch_dt=None, residual=None):
         if self.mode != "no-fourier":
-            x = self.forward_fourier(x)
+            if residual is x and torch.is_grad_enabled() and x.requires_grad:
+                x, residual = self.forward_fourier(x, with_skip=True)
+            else:
+                x = self.forward_fourier(x)
         b = self.backcast_ff(x, residual=residual)
         f = self.forecast_ff(x) if self.use_fork else None
         return b, f

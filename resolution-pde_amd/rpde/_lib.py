@@ -43,7 +43,7 @@ class GemmDesc(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64),
         ("write_act", C.c_int), ("drop_where", C.c_int),
-        ("colsum", C.c_void_p), ("aux_out", C.c_void_p), ("b_split", C.c_void_p), ("a_split", C.c_void_p),
+        ("colsum", C.c_void_p), ("aux_out", C.c_void_p), ("b_split", C.c_void_p), ("a_split", C.c_void_p), ("acc_src", C.c_void_p),
     ]
 
 
@@ -75,11 +75,11 @@ _SIGNATURES = {
     "rpde_fspectral1d_ws_bytes": (_Z, [_I, _I, _I, _I]),
     "rpde_fspectral1d_spec_elems": (_Z, [_I, _I, _I, _I]),
     "rpde_fspectral1d_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "rpde_fspectral1d_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "rpde_fspectral1d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_fspectral2d_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "rpde_fspectral2d_spec_elems": (_Z, [_I, _I, _I, _I, _I, _I]),
     "rpde_fspectral2d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
-    "rpde_fspectral2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "rpde_fspectral2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_spectral1d_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "rpde_spectral1d_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_spectral1d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),

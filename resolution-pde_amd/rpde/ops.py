@@ -33,7 +33,7 @@ def _as_float_storage(w: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------
 class _FSpectral1d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, modes: int, mode: int, norm: int):
+    def forward(ctx, x, w, modes: int, mode: int, norm: int, with_skip: bool = False):
         lib = load()
         x = _f32c(x)
         wf = _f32c(w) if w is not None else None
@@ -46,27 +46,33 @@ class _FSpectral1d(torch.autograd.Function):
                                        ws.data_ptr(), nws, stream_ptr()), "fspectral1d_fwd")
         ctx.save_for_backward(spec, wf if wf is not None else x.new_empty(0))
         ctx.dims = (B, n, Cc, modes, mode, norm, wf is not None)
-        return out
+        # with_skip: also hand x back (an alias) for the caller's skip connection, so that the gradient
+        # arriving through the skip is summed by the last backward GEMM's epilogue, not by a separate pass
+        return (out, x.view_as(x)) if with_skip else out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_skip=None):
         lib = load()
         spec, wf = ctx.saved_tensors
         B, n, Cc, modes, mode, norm, has_w = ctx.dims
+        if g is None:
+            return g_skip, None, None, None, None, None
         g = _f32c(g)
+        g_skip = _f32c(g_skip) if g_skip is not None else None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and has_w
         gx = torch.empty_like(g) if need_x else None
         gw = torch.empty_like(wf) if need_w else None
         nws = lib.rpde_fspectral1d_ws_bytes(B, n, Cc, modes)
         ws = workspace(nws, g.device)
-        check(lib.rpde_fspectral1d_bwd(ptr(g), ptr(spec), ptr(wf) if has_w else None, ptr(gx), ptr(gw), B, n, Cc, modes,
+        check(lib.rpde_fspectral1d_bwd(ptr(g), ptr(spec), ptr(wf) if has_w else None, ptr(gx), ptr(gw),
+                                       ptr(g_skip) if need_x else None, B, n, Cc, modes,
                                        mode, norm, ws.data_ptr(), nws, stream_ptr()), "fspectral1d_bwd")
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None
 
 
 class _FSpectral2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wy, wx, modes: int, mode: int):
+    def forward(ctx, x, wy, wx, modes: int, mode: int, with_skip: bool = False):
         lib = load()
         x = _f32c(x)
         has_w = wy is not None
@@ -85,17 +91,20 @@ class _FSpectral2d(torch.autograd.Function):
         else:
             ctx.save_for_backward(spec_y, spec_x)
         ctx.dims = (B, M, N, Cc, modes, mode, has_w)
-        return out
+        return (out, x.view_as(x)) if with_skip else out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_skip=None):
         lib = load()
         B, M, N, Cc, modes, mode, has_w = ctx.dims
+        if g is None:
+            return g_skip, None, None, None, None, None
         if has_w:
             spec_y, spec_x, wyf, wxf = ctx.saved_tensors
         else:
             (spec_y, spec_x), wyf, wxf = ctx.saved_tensors, None, None
         g = _f32c(g)
+        g_skip = _f32c(g_skip) if g_skip is not None else None
         need_x = ctx.needs_input_grad[0]
         need_w = has_w and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         gx = torch.empty_like(g) if need_x else None
@@ -104,24 +113,27 @@ class _FSpectral2d(torch.autograd.Function):
         nws = lib.rpde_fspectral2d_ws_bytes(B, M, N, Cc, modes)
         ws = workspace(nws, g.device)
         check(lib.rpde_fspectral2d_bwd(ptr(g), ptr(spec_y), ptr(spec_x), ptr(wyf), ptr(wxf), ptr(gx), ptr(gwy), ptr(gwx),
+                                       ptr(g_skip) if need_x else None,
                                        B, M, N, Cc, modes, mode, ws.data_ptr(), nws, stream_ptr()), "fspectral2d_bwd")
-        return gx, gwy, gwx, None, None
+        return gx, gwy, gwx, None, None, None
 
 
-def fspectral1d(x, w, modes: int, mode: str = "full", norm: str = "ortho"):
-    """FSpectralConv1d.forward_fourier: x [B,n,C], w [C,C,K,2]."""
+def fspectral1d(x, w, modes: int, mode: str = "full", norm: str = "ortho", with_skip: bool = False):
+    """FSpectralConv1d.forward_fourier: x [B,n,C], w [C,C,K,2].
+    with_skip: returns (out, x') where x' aliases x -- use x' for a skip connection around the layer and
+    its gradient is folded into the backward's last GEMM instead of a separate add."""
     if mode not in MODE:
         raise ValueError(f"Mode {mode} not recognized")
-    return _FSpectral1d.apply(x, w if mode == "full" else None, int(modes), MODE[mode], NORM[norm])
+    return _FSpectral1d.apply(x, w if mode == "full" else None, int(modes), MODE[mode], NORM[norm], bool(with_skip))
 
 
-def fspectral2d(x, wy, wx, modes: int, mode: str = "full"):
-    """FSpectralConv2d.forward_fourier: x [B,M,N,C], w_y/w_x [C,C,K,2]."""
+def fspectral2d(x, wy, wx, modes: int, mode: str = "full", with_skip: bool = False):
+    """FSpectralConv2d.forward_fourier: x [B,M,N,C], w_y/w_x [C,C,K,2].  with_skip: see fspectral1d."""
     if mode not in MODE:
         # the reference's 2-D layer has no else branch: both spectra stay zero
-        return torch.zeros_like(x)
+        return (torch.zeros_like(x), x) if with_skip else torch.zeros_like(x)
     full = mode == "full"
-    return _FSpectral2d.apply(x, wy if full else None, wx if full else None, int(modes), MODE[mode])
+    return _FSpectral2d.apply(x, wy if full else None, wx if full else None, int(modes), MODE[mode], bool(with_skip))
 
 
 # ----------------------------------------------------------------------------
