@@ -126,15 +126,18 @@ def time_ff_gemm(B, device, iters=20):
                   "frac": round(byt / (t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "ms_per_launch": round(t, 4),
                   "fp32_equiv_tflops": round(flops / (t * 1e-3) / 1e12, 2)})
     f = base()                                           # weight gradient: W' = g^T @ h, split over the points
-    S = 128
+    S = 192                                              # = rpde_feedforward_bwd: 768 workgroups / 4 tiles
     slabs = torch.empty(S * N * K, device=device)
     f.A, f.B, f.C = h2.data_ptr(), h1.data_ptr(), slabs.data_ptr()
     f.M, f.N, f.K, f.a_kmajor, f.b_kmajor = N, K, P, 0, 0
     f.lda, f.ldb, f.ldc, f.ksplit, f.sCk = N, K, K, S, N * K
     t = _time_gemm(f, max(5, iters // 2))
-    extra.append({"kernel": "gemm_f32 TN weight gradient [256,P]x[P,256], split-K 128 slabs", "bound": "mfma",
-                  "achieved": round(flops / (t * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                  "frac": round(flops / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TF, 4), "ms_per_launch": round(t, 4)})
+    # 69 flop/B (reads g and h once) is above the split path's ridge (417 TF / 8 TB/s = 52): matrix bound
+    extra.append({"kernel": "gemm split-bf16 TN weight gradient [256,P]x[P,256] (transposing LDS reads), split-K 192 slabs",
+                  "bound": "mfma", "achieved": round(flops / (t * 1e-3) / 1e12, 2), "peak": round(PEAK_BF16_MFMA_TF / 6, 1),
+                  "unit": "TFLOP/s (fp32-equivalent: 6 bf16 MFMA flops per fp32 flop)",
+                  "frac": round(flops / (t * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TF / 6), 4), "ms_per_launch": round(t, 4),
+                  "hbm_gbs": round(8.0 * P * N / (t * 1e-3) / 1e9, 1)})
     alg_bytes = 4.0 * P * (K + 2 * N) + 4.0 * N * K         # read h1, write h2 and d2, read W2
     return ms, flops / (ms * 1e-3) / 1e12, flops, extra, alg_bytes
 

@@ -25,7 +25,7 @@ static inline int ff_out(const rpde_ff_params* p, int l) { return l == p->n_laye
 
 static inline int wgrad_split(long P, int out_f, int in_f) {
   const int tiles = ((out_f + 127) / 128) * ((in_f + 127) / 128);
-  long s = 512 / tiles;          // 2 resident workgroups per CU, one wave of them
+  long s = 768 / tiles;          // 3 resident workgroups per CU (split-bf16 kernel), one wave of them
   const long cap = (P + 127) / 128;
   if (s > cap) s = cap;
   if (s < 1) s = 1;

@@ -186,18 +186,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   char* const Bs = smem_raw + 3 * TA::IMG_BYTES;
 
   const int tid = threadIdx.x;
-  const int L = blockIdx.x;
-  int mt, nt;
-  if (g.swz) {
-    mt = (L / (8 * g.ntiles)) * 8 + (L & 7);
-    nt = (L >> 3) % g.ntiles;
-    if (mt >= g.mtiles) return;
-  } else {
-    mt = L / g.ntiles;
-    nt = L - mt * g.ntiles;
-  }
-  const int zz = blockIdx.z * gridDim.y + blockIdx.y;
-  if (zz >= g.ztotal) return;
+  int mt, nt, zz;
+  if (!tile_coords(g, mt, nt, zz)) return;
   const int z = zz / g.ksplit, ks = zz - z * g.ksplit;
   const int z1 = z / g.zdiv, z2 = z - z1 * g.zdiv;
   const float* __restrict__ A = g.A + z1 * g.sA1 + z2 * g.sA2;

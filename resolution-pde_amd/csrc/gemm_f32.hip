@@ -60,7 +60,9 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   const long zt = (long)g.ztotal;
   const int gy = (int)(zt < 32768 ? zt : 32768);
   const int gz = (int)((zt + gy - 1) / gy);
-  dim3 grid(g.swz ? ((g.mtiles + 7) / 8) * 8 * g.ntiles : g.mtiles * g.ntiles, gy, gz);
+  const int tiles = g.mtiles * g.ntiles;
+  if (!g.swz && tiles > 1 && tiles <= 16 && gz == 1 && zt % 8 == 0) g.swz = 2;
+  dim3 grid(g.swz == 1 ? ((g.mtiles + 7) / 8) * 8 * g.ntiles : g.mtiles * g.ntiles, gy, gz);
 
   // LDS-staged vector epilogue: C rows, aux rows, bias and the dropout ids must be 16-byte friendly
   g.cvec = vec && al16(d.C) && (d.ldc % 4 == 0) && (d.sC1 % 4 == 0) && (d.sC2 % 4 == 0) && (d.sCk % 4 == 0) &&

@@ -163,6 +163,34 @@ struct Tile {
 
 // PRO: 0 no staged activation, 1 on A, 2 on B.  BK: k-extent of a stage; STAGES: LDS stages (2 = double
 // buffered, one barrier per stage; 1 = single buffer, two barriers, half the LDS -> more resident waves)
+// Which C tile and which (batch entry, K slab) this workgroup owns.  Workgroups go round-robin to the 8 XCDs
+// in dispatch order and each XCD has its own L2, so tiles that re-read the same operand rows should share an
+// XCD:  swz = 1 (many M-tiles): the N-tiles of one M-tile sit 8 apart in the linear id;
+//       swz = 2 (few tiles, many K slabs / batch entries): the T tiles of one slab sit 8 apart, so each
+//       slab's operands cross the fabric once instead of once per tile (measured with FETCH_SIZE: the 2x2-tile
+//       weight gradient read its operands twice, 8.6 GB per launch instead of 4.3).
+__device__ __forceinline__ bool tile_coords(const GemmK& g, int& mt, int& nt, int& zz) {
+  const int L = blockIdx.x;
+  zz = blockIdx.z * gridDim.y + blockIdx.y;
+  if (g.swz == 1) {
+    mt = (L / (8 * g.ntiles)) * 8 + (L & 7);
+    nt = (L >> 3) % g.ntiles;
+    if (mt >= g.mtiles) return false;
+  } else if (g.swz == 2) {
+    const int T = g.mtiles * g.ntiles;                 // = gridDim.x, gridDim.z == 1, ztotal % 8 == 0
+    const long lin = (long)blockIdx.y * T + L;
+    const int grp = (int)(lin / (8 * T)), r = (int)(lin - (long)grp * 8 * T);
+    zz = grp * 8 + (r & 7);
+    const int tile = r >> 3;
+    mt = tile / g.ntiles;
+    nt = tile - mt * g.ntiles;
+  } else {
+    mt = L / g.ntiles;
+    nt = L - mt * g.ntiles;
+  }
+  return zz < g.ztotal;
+}
+
 template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PRO, bool VEC, int BK = 32, int STAGES = 2, bool PIPE = false,
           bool PREAUX = false>
 __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(const GemmK g) {
@@ -184,18 +212,8 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
 
   const int tid = threadIdx.x;
   // ---- which tile, which batch entry, which K slice -------------------------
-  const int L = blockIdx.x;
-  int mt, nt;
-  if (g.swz) {
-    mt = (L / (8 * g.ntiles)) * 8 + (L & 7);
-    nt = (L >> 3) % g.ntiles;
-    if (mt >= g.mtiles) return;
-  } else {
-    mt = L / g.ntiles;
-    nt = L - mt * g.ntiles;
-  }
-  const int zz = blockIdx.z * gridDim.y + blockIdx.y;
-  if (zz >= g.ztotal) return;
+  int mt, nt, zz;
+  if (!tile_coords(g, mt, nt, zz)) return;
   const int z = zz / g.ksplit, ks = zz - z * g.ksplit;
   const int z1 = z / g.zdiv, z2 = z - z1 * g.zdiv;
   const float* __restrict__ A = g.A + z1 * g.sA1 + z2 * g.sA2;

@@ -77,6 +77,10 @@ def test_gemm_batched_bias_accumulate(gpu_device):
 def test_gemm_split_k(gpu_device):
     assert _gemm(gpu_device, 256, 256, 5000, 0, 0, ksplit=7) < 4e-6
     assert _gemm(gpu_device, 64, 3, 4097, 0, 0, ksplit=16, batch=2) < 4e-6
+    # few tiles x many slabs: the XCD-grouped workgroup order (slabs of one tile set share an L2)
+    assert _gemm(gpu_device, 256, 256, 8192, 0, 0, ksplit=16) < 4e-6
+    assert _gemm(gpu_device, 200, 130, 4096, 0, 0, ksplit=8, batch=3) < 4e-6
+    assert _gemm(gpu_device, 64, 256, 2048, 0, 0, ksplit=24) < 4e-6
 
 
 def test_gemm_activation_prologue_and_store(gpu_device):
