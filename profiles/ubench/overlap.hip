@@ -1,13 +1,45 @@
-// Does VALU work of one wave overlap with bf16 / fp32 MFMA work of another wave on the same SIMD?
+// Does VALU work of one wave overlap with bf16 MFMA work of another wave on the same SIMD, and which
+// VALU instruction kinds do?  (MI355X_MICROARCH.md price list: an MFMA holds the vector issue port for 8 of
+// its 32 cycles; packed fp32 VALU is an "anti-lever" beside MFMAs.)
 // Build: hipcc --offload-arch=gfx950 -O3 overlap.hip -o overlap ; run: ./overlap
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int MODE>  // bit0: MFMA waves active, bit1: VALU waves active, bit2: fp32 mfma instead of bf16
+// KIND: 0 v_fma_f32 (4 chains), 1 v_pk_fma_f32, 2 v_cvt_pk_bf16_f32 + v_lshlrev (split-like), 3 v_mul_lo_u32, 4 v_exp_f32
+template <int KIND>
+__device__ __forceinline__ void valu_block(float& v0, float& v1, float& v2, float& v3) {
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    if (KIND == 0) {
+      asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5"
+                   : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(1.0001f), "v"(0.5f));
+    } else if (KIND == 1) {
+      f2 a = {v0, v1}, b = {v2, v3};
+      asm volatile("v_pk_fma_f32 %0, %0, %2, %3\n v_pk_fma_f32 %1, %1, %2, %3\n v_pk_fma_f32 %0, %0, %2, %3\n v_pk_fma_f32 %1, %1, %2, %3"
+                   : "+v"(a), "+v"(b) : "v"((f2){1.0001f, 0.9999f}), "v"((f2){0.5f, 0.25f}));
+      v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+    } else if (KIND == 2) {
+      unsigned p, q;
+      asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n v_lshlrev_b32 %1, 16, %0\n v_cvt_pk_bf16_f32 %0, %4, %5\n v_and_b32 %1, 0xffff0000, %0"
+                   : "=&v"(p), "=&v"(q) : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+      v0 += __uint_as_float(q);
+    } else if (KIND == 3) {
+      unsigned a = __float_as_uint(v0), b = __float_as_uint(v1), c = __float_as_uint(v2), d = __float_as_uint(v3);
+      asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4"
+                   : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(0x7feb352du));
+      v0 = __uint_as_float(a); v1 = __uint_as_float(b); v2 = __uint_as_float(c); v3 = __uint_as_float(d);
+    } else {
+      asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+    }
+  }
+}
+
+template <int MODE, int KIND>  // MODE bit0: MFMA waves active, bit1: VALU waves active
 __global__ __launch_bounds__(512) void k(float* out, int iters) {
-  const int wave = threadIdx.x >> 6;  // 8 waves: waves 0-3 -> one per SIMD do MFMA, 4-7 do VALU
+  const int wave = threadIdx.x >> 6;  // 8 waves: waves 0-3 (one per SIMD) do MFMA, 4-7 do VALU
   f16v acc = {0};
   float v0 = threadIdx.x, v1 = 1.0f, v2 = 0.5f, v3 = 0.25f;
   if (wave < 4) {
@@ -16,43 +48,39 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
       for (int i = 0; i < 8; i++) { a[i] = (__bf16)1.0f; b[i] = (__bf16)0.5f; }
       for (int it = 0; it < iters; it++) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-          if (MODE & 4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, v2, acc, 0, 0, 0);
-          else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-        }
+        for (int j = 0; j < 16; j++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
       }
     }
-  } else {
-    if (MODE & 2) {
-      for (int it = 0; it < iters; it++) {
-#pragma unroll
-        for (int j = 0; j < 32; j++) {  // 4 independent chains: 128 v_fma per iteration
-          v0 = __builtin_fmaf(v0, 1.0001f, 0.5f); v1 = __builtin_fmaf(v1, 0.9999f, 0.25f);
-          v2 = __builtin_fmaf(v2, 1.0002f, 0.125f); v3 = __builtin_fmaf(v3, 0.9998f, 0.0625f);
-        }
-      }
-    }
+  } else if (MODE & 2) {
+    for (int it = 0; it < iters; it++) valu_block<KIND>(v0, v1, v2, v3);
   }
   float s = v0 + v1 + v2 + v3;
   for (int i = 0; i < 16; i++) s += acc[i];
   if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
-template <int MODE> float run(float* d, int iters) {
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k<MODE><<<256, 512>>>(d, 10);
-  hipEventRecord(e0);
-  k<MODE><<<256, 512>>>(d, iters);
-  hipEventRecord(e1); hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1); return ms;
+template <int MODE, int KIND> float run(float* d, int iters) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  k<MODE, KIND><<<256, 512>>>(d, 10);
+  (void)hipEventRecord(e0);
+  k<MODE, KIND><<<256, 512>>>(d, iters);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); return ms;
+}
+template <int KIND> void report(const char* name, float* d, int it, float mf) {
+  const float v = run<2, KIND>(d, it), b = run<3, KIND>(d, it);
+  printf("%-28s alone %.3f ms   with MFMA wave %.3f ms   (mfma alone %.3f; sum %.3f, max %.3f)\n", name, v, b, mf, v + mf, v > mf ? v : mf);
 }
 int main() {
-  float* d; hipMalloc(&d, 4096);
+  float* d; (void)hipMalloc(&d, 4096);
   const int it = 20000;
-  printf("bf16 mfma only   %.3f ms (16 mfma x %d)\n", run<1>(d, it), it);
-  printf("valu only        %.3f ms (128 fma x %d)\n", run<2>(d, it), it);
-  printf("bf16 mfma + valu %.3f ms\n", run<3>(d, it));
-  printf("fp32 mfma only   %.3f ms\n", run<5>(d, it));
-  printf("fp32 mfma + valu %.3f ms\n", run<7>(d, it));
+  const float mf = run<1, 0>(d, it);
+  printf("bf16 mfma only (16 x %d per wave): %.3f ms; VALU waves issue 128 instructions x %d\n", it, mf, it);
+  report<0>("v_fma_f32", d, it, mf);
+  report<1>("v_pk_fma_f32", d, it, mf);
+  report<2>("v_cvt_pk_bf16 + shift/and", d, it, mf);
+  report<3>("v_mul_lo_u32", d, it, mf);
+  report<4>("v_exp_f32", d, it, mf);
   return 0;
 }

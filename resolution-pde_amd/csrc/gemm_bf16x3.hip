@@ -25,22 +25,38 @@
 
 namespace rpde {
 
+// RPDE_STAMPS (debug builds only: rpde/build.py --stamps): wave 0 of 64 mid-launch workgroups records
+// s_memtime at its phase boundaries; rpde_debug_stamps() copies them out.  profiles/stamps.py prints them.
+#ifdef RPDE_STAMPS
+__device__ unsigned long long g_stamps[64 * 32];
+#define STAMP(i) do { if (stamp_on) g_stamps[stamp_slot * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_RT(i) do { if (stamp_on) g_stamps[stamp_slot * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#define STAMP_RT(i) do { } while (0)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int XBK = 32;
 
-// three bf16 pieces of two floats, packed pairwise (low half = first element)
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+// three bf16 pieces of two floats, packed pairwise (low half = first element).
+// Scalar subtractions on purpose (and -fno-slp-vectorize in the build): packed fp32 VALU (v_pk_add_f32 ...)
+// does not overlap with MFMAs of the other waves on the SIMD, ordinary VALU does
+// (profiles/ubench/overlap.hip: v_fma_f32 beside an MFMA wave costs 30 % of the MFMA time, v_pk_fma_f32 100 %).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  union { bf16x2 v; unsigned u; } ph, pm, pl;
-  f32x2 x = {x0, x1};
-  ph.v = __builtin_convertvector(x, bf16x2);
-  f32x2 r1 = x - __builtin_convertvector(ph.v, f32x2);
-  pm.v = __builtin_convertvector(r1, bf16x2);
-  f32x2 r2 = r1 - __builtin_convertvector(pm.v, f32x2);
-  pl.v = __builtin_convertvector(r2, bf16x2);
-  h = ph.u; m = pm.u; l = pl.u;
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  union { bf16x2 v; unsigned u; } p;
+  p.v = __builtin_convertvector((f32x2_){a, b}, bf16x2);
+  return p.u;
+}
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(r0, r1);
+  const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = cvt_pk_bf16(q0, q1);
 }
 
 // byte offset of element (row, k) inside one [ROWS][32] bf16 image
@@ -202,6 +218,14 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
+#ifdef RPDE_STAMPS
+  const long stamp_lin = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  const long stamp_first = ((long)gridDim.x * gridDim.y / 2) & ~63L;
+  const bool stamp_on = tid == 0 && stamp_lin >= stamp_first && stamp_lin < stamp_first + 64;
+  const int stamp_slot = (int)(stamp_lin - stamp_first);
+#endif
+  STAMP(0);
+  STAMP_RT(31);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -245,10 +269,13 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   }
   // (a second register set fetching two stages ahead was measured slower here: the extra 32 VGPRs cost
   //  a resident wave, and three workgroups per CU already cover the load latency)
+  STAMP(1);
   for (int kt = 0; kt < nkt; ++kt) {
     if (AIMG) bimg_store<NBI>(As + tid * 16, rbi, TA::IMG_BYTES); else TA::store(As, ra, tid);
     if (BIMG) bimg_store<NBI>(Bs + tid * 16, rbi, TB::IMG_BYTES); else TB::store(Bs, rb, tid);
+    if (kt < 8) STAMP(2 + 3 * kt);
     __syncthreads();
+    if (kt < 8) STAMP(3 + 3 * kt);
     if (kt + 1 < nkt) {
       at += astep; bt += bstep; bimg += bimg_step;
       if (!AIMG) TA::load(ra, at, oa);
@@ -283,7 +310,10 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
         }
     }
     __syncthreads();
+    if (kt < 8) STAMP(4 + 3 * kt);
   }
+  STAMP(26);
+  STAMP_RT(25);   // (overwrites k7's last stamp: constant-rate clock at loop end, for the shader frequency)
 
   // ---- epilogue (same as the fp32 kernel's vector path; the host only dispatches here when g.cvec) ----
   const bool drop_e = g.drop.on() && (g.drop_where & 4);
@@ -304,6 +334,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   const bool fast_mul = plain && g.epi_dact == RPDE_EPI_MULAUX && !g.write_act;
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
+    if (e == 1) STAMP(29);
     if (e > 0) __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -318,12 +349,13 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
       }
     }
     __syncthreads();
+    if (e == 0) STAMP(28); else STAMP(30);
     if (gn < g.N) {
       // the mode is uniform over the launch: pick the row loop once, not per element
       if (fast_hd) {
-        // C = gelu(u), aux_out = gelu'(u) * dropscale, u = dropout(alpha*acc + bias): packed fp32 math
+        // C = gelu(u), aux_out = gelu'(u) * dropscale, u = dropout(alpha*acc + bias)
         float* __restrict__ dout = g.aux_out + coff;
-#pragma unroll 2
+#pragma unroll 4
         for (int it = 0; it < NV4; ++it) {
           const int row = row0 + it * RSTEP;
           const int gm = m0 + e * SLAB + row;
@@ -331,17 +363,17 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
           const float4 t = *reinterpret_cast<const float4*>(cs + row * BN + c4);
           float s[4] = {1.f, 1.f, 1.f, 1.f};
           if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
-          const f32x2 s01 = {s[0], s[1]}, s23 = {s[2], s[3]};
-          const f32x2 al = (f32x2)(g.alpha);
-          const f32x2 u01 = __builtin_elementwise_fma((f32x2){t.x, t.y}, al, (f32x2){bn4.x, bn4.y}) * s01;
-          const f32x2 u23 = __builtin_elementwise_fma((f32x2){t.z, t.w}, al, (f32x2){bn4.z, bn4.w}) * s23;
-          f32x2 h01, d01, h23, d23;
-          gelu_both2(u01, h01, d01);
-          gelu_both2(u23, h23, d23);
-          d01 *= s01; d23 *= s23;
-          *reinterpret_cast<float4*>(dout + (long)gm * g.ldc + gn) = make_float4(d01.x, d01.y, d23.x, d23.y);
-          *reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn) = make_float4(h01.x, h01.y, h23.x, h23.y);
-          csum.x += h01.x; csum.y += h01.y; csum.z += h23.x; csum.w += h23.y;
+          const float u0 = fmaf(t.x, g.alpha, bn4.x) * s[0], u1 = fmaf(t.y, g.alpha, bn4.y) * s[1];
+          const float u2 = fmaf(t.z, g.alpha, bn4.z) * s[2], u3 = fmaf(t.w, g.alpha, bn4.w) * s[3];
+          // (scalar on purpose: a packed-fp32 version, 11 instead of 20 issues per element, measured 0.5 % slower
+          //  end to end -- v_pk_* instructions do not overlap with the other waves' MFMAs)
+          float4 hv, dv;
+          act_both(RPDE_ACT_GELU, u0, hv.x, dv.x); act_both(RPDE_ACT_GELU, u1, hv.y, dv.y);
+          act_both(RPDE_ACT_GELU, u2, hv.z, dv.z); act_both(RPDE_ACT_GELU, u3, hv.w, dv.w);
+          dv.x *= s[0]; dv.y *= s[1]; dv.z *= s[2]; dv.w *= s[3];
+          *reinterpret_cast<float4*>(dout + (long)gm * g.ldc + gn) = dv;
+          *reinterpret_cast<float4*>(C + (long)gm * g.ldc + gn) = hv;
+          csum.x += hv.x; csum.y += hv.y; csum.z += hv.z; csum.w += hv.w;
         }
       } else if (fast_mul) {
         // C = (alpha*acc + bias) * aux: backward-data through the stored derivative
@@ -405,6 +437,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
       }
     }
   }
+  STAMP(27);
   if (g.colsum) {
     __syncthreads();
     *reinterpret_cast<float4*>(cs + row0 * BN + c4) = csum;
@@ -480,6 +513,13 @@ int launch_bf16x3(const GemmK& g, int bm, int bn, bool ak, bool bk, dim3 grid, h
 
 }  // namespace rpde
 
+#ifdef RPDE_STAMPS
+extern "C" int rpde_debug_stamps(unsigned long long* host_out) {
+  RPDE_HIP(hipDeviceSynchronize());
+  RPDE_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rpde::g_stamps), sizeof(unsigned long long) * 64 * 32));
+  return RPDE_OK;
+}
+#endif
 extern "C" size_t rpde_split_weights_bytes(int N, int K) { return (N > 0 && K > 0) ? rpde::split_bytes(N, K) : 0; }
 extern "C" int rpde_split_weights(const float* w, int kmajor, int64_t ld, int N, int K, void* out, void* stream) {
   return rpde::split_weights(w, kmajor, (long)ld, N, K, out, rpde::as_stream(stream));

@@ -49,8 +49,7 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // library's erff (~100).  Measured in fp32 against scipy over [-9, 9]: |Phi error| <= 3.0e-7,
 // |gelu error| <= 4.2e-7, |gelu' error| <= 3.2e-7 (parity budget of the hot path: 1e-5).
 // (constants folded: s = 1/(1 + p/sqrt2 |x|), the 0.5 of 0.5 erfc into the coefficients, exp(-x^2/2) as
-//  exp2(-x^2 log2(e)/2); the scalar and the packed two-element form below run the same operations in the
-//  same order, so they agree bit for bit)
+//  exp2(-x^2 log2(e)/2))
 __device__ __forceinline__ void phi_parts(float x, float& cdf, float& gauss) {
   const float s = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, fabsf(x), 1.0f));
   gauss = __builtin_amdgcn_exp2f((x * x) * -0.72134752044f);      // = exp(-x^2 / 2)
@@ -61,28 +60,7 @@ __device__ __forceinline__ void phi_parts(float x, float& cdf, float& gauss) {
   const float half = (p * s) * gauss;                           // 0.5 erfc(|x| / sqrt 2)
   cdf = x < 0.f ? half : 1.0f - half;
 }
-// two elements at once on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32): h = gelu(u), d = gelu'(u).
-// 11 VALU issues per element instead of ~20: on gfx950 VALU and MFMA issue serially on a SIMD, so the
-// activation epilogue of the FeedForward GEMMs is paid in matrix throughput.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gelu_both2(f32x2 u, f32x2& h, f32x2& d) {
-  f32x2 s, g;
-  s.x = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, fabsf(u.x), 1.0f));
-  s.y = __builtin_amdgcn_rcpf(fmaf(0.2316418882f, fabsf(u.y), 1.0f));
-  const f32x2 e = (u * u) * (f32x2)(-0.72134752044f);
-  g.x = __builtin_amdgcn_exp2f(e.x);
-  g.y = __builtin_amdgcn_exp2f(e.y);
-  f32x2 p = __builtin_elementwise_fma((f32x2)(0.5307027145f), s, (f32x2)(-0.7265760135f));
-  p = __builtin_elementwise_fma(p, s, (f32x2)(0.7107068705f));
-  p = __builtin_elementwise_fma(p, s, (f32x2)(-0.142248368f));
-  p = __builtin_elementwise_fma(p, s, (f32x2)(0.127414796f));
-  const f32x2 half = (p * s) * g;
-  f32x2 c;
-  c.x = u.x < 0.f ? half.x : 1.0f - half.x;
-  c.y = u.y < 0.f ? half.y : 1.0f - half.y;
-  h = u * c;
-  d = __builtin_elementwise_fma(u * g, (f32x2)(0.39894228040143267794f), c);
-}
 __device__ __forceinline__ float norm_cdf_f(float x) {
   float c, g;
   phi_parts(x, c, g);

@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librpde_hip.so")
+# RPDE_LIB: load another build of the same library (the timestamp-instrumented debug variant)
+LIB_PATH = os.environ.get("RPDE_LIB") or os.path.join(_HERE, "lib", "librpde_hip.so")
 
 ACT = {"identity": 0, "gelu": 1, "relu": 2}
 NORM = {"backward": 0, "ortho": 1, "forward": 2}

@@ -24,7 +24,10 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librpde_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
-         "-Wno-unused-result"]
+         "-Wno-unused-result",
+         # packed fp32 VALU does not overlap with the matrix pipe on gfx950 (profiles/ubench/overlap.hip):
+         # keep the compiler from pairing scalar fp32 adds / multiplies into v_pk_* instructions
+         "-fno-slp-vectorize"]
 
 
 def _hipcc() -> str:
@@ -44,7 +47,14 @@ def _newest_header() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> str:
+    """stamps=True: debug variant with in-kernel phase timestamps (RPDE_STAMPS) -> lib/librpde_hip_stamps.so,
+    loaded instead of the product library when RPDE_LIB points at it (profiles/stamps.py)."""
+    global OBJDIR, LIB
+    if stamps:
+        OBJDIR, LIB = os.path.join(REPO, "build", "rpde_stamps"), os.path.join(LIBDIR, "librpde_hip_stamps.so")
+        if "-DRPDE_STAMPS" not in FLAGS:
+            FLAGS.append("-DRPDE_STAMPS")
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hdr = _newest_header()
@@ -80,4 +90,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, stamps="--stamps" in sys.argv)
