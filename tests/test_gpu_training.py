@@ -138,3 +138,49 @@ def test_all_resolution_evaluator_and_rollouts(gpu_device):
                 layer_norm=True).to(gpu_device)
     p1 = perform_rollout_1d(m1, torch.randn(5, 64, device=gpu_device), 4, device=gpu_device)
     assert p1.shape == (5, 4, 64) and torch.isfinite(p1).all()
+
+
+@pytest.mark.parametrize("dims", [1, 2])
+def test_skip_gradient_folded_into_spectral_backward(gpu_device, dims):
+    """ops.fspectral{1,2}d(..., with_skip=True) hands x back as an alias for the skip connection; the gradient
+    arriving through it is added by the last backward GEMM (rpde_gemm_desc.acc_src).  Same numbers as the
+    plain formulation x + f(spectral(x)) whose two gradients autograd adds in a separate pass."""
+    from rpde import ops
+    torch.manual_seed(5)
+    C, K = 16, 6
+    shape = (3, 40, C) if dims == 1 else (2, 24, 40, C)
+    x0 = torch.randn(*shape, device=gpu_device)
+    ws = [(torch.randn(C, C, K, 2, device=gpu_device) * 0.2).requires_grad_() for _ in range(dims)]
+    probe = torch.randn(*shape, device=gpu_device)
+
+    def run(with_skip):
+        x = x0.clone().requires_grad_()
+        for w in ws:
+            w.grad = None
+        if dims == 1:
+            out = ops.fspectral1d(x, ws[0], K, with_skip=with_skip)
+        else:
+            out = ops.fspectral2d(x, ws[0], ws[1], K, with_skip=with_skip)
+        y, skip = out if with_skip else (out, x)
+        z = torch.tanh(y) * 0.7 + skip * 1.3          # both branches used, with different weights
+        (z * probe).sum().backward()
+        return z.detach(), x.grad.clone(), [w.grad.clone() for w in ws]
+
+    z0, gx0, gw0 = run(False)
+    z1, gx1, gw1 = run(True)
+    assert torch.equal(z0, z1)
+    assert float((gx0 - gx1).norm() / gx0.norm()) < 1e-6
+    for a, b in zip(gw0, gw1):
+        assert torch.equal(a, b)
+    # and a model-level check: the FFNO layer takes this route when the residual is its own input
+    from models.spectral_convolution import FSpectralConv2d
+    layer = FSpectralConv2d(C, K, factor=2, n_ff_layers=2, layer_norm=True).to(gpu_device)
+    h = torch.randn(2, 16, 16, C, device=gpu_device, requires_grad=True)
+    b, _ = layer(h, residual=h)
+    b.sum().backward()
+    g_fused = h.grad.clone()
+    h.grad = None
+    hh = h.detach().clone().requires_grad_()
+    b2, _ = layer(hh, residual=hh.detach() * 1.0)      # a different tensor object: plain route, skip not differentiated
+    (b2.sum() + hh.sum()).backward()                   # d(residual)/dh = 1 added by hand
+    assert float((hh.grad - g_fused).norm() / g_fused.norm()) < 1e-6
