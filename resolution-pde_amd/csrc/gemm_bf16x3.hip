@@ -286,28 +286,46 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
     }
 #pragma unroll
     for (int s = 0; s < XBK / 16; ++s) {
-      bf16x8 af[TM][3], bf[TN][3];
+      // two rounds so that only 8 fragments (32 VGPRs) are live at a time: (hi, mid) of both operands first,
+      // then the low images take over the registers of the mid ones
+      bf16x8 a0[TM], a1[TM], b0[TN], b1[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        a0[i] = TA::frag(As, fa[i], 0, (wm * TM + i) * 32 + l31, lh, s);
+        a1[i] = TA::frag(As, fa[i], 1, (wm * TM + i) * 32 + l31, lh, s);
+      }
 #pragma unroll
-        for (int w = 0; w < 3; ++w) af[i][w] = TA::frag(As, fa[i], w, (wm * TM + i) * 32 + l31, lh, s);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int w = 0; w < 3; ++w) bf[j][w] = TB::frag(Bs, fb[j], w, (wn * TN + j) * 32 + l31, lh, s);
+      for (int j = 0; j < TN; ++j) {
+        b0[j] = TB::frag(Bs, fb[j], 0, (wn * TN + j) * 32 + l31, lh, s);
+        b1[j] = TB::frag(Bs, fb[j], 1, (wn * TN + j) * 32 + l31, lh, s);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          f32x16 c = acc[i][j];        // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], c, 0, 0, 0);
           acc[i][j] = c;
         }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 a2[TM], b2[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a2[i] = TA::frag(As, fa[i], 2, (wm * TM + i) * 32 + l31, lh, s);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b2[j] = TB::frag(Bs, fb[j], 2, (wn * TN + j) * 32 + l31, lh, s);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b2[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b0[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     if (kt < 8) STAMP(4 + 3 * kt);
