@@ -37,18 +37,29 @@ def train_step(model, x, y):
     return step
 
 
+def graphed(model, x, y):
+    from rpde.graph import GraphedTrainStep
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True)
+    step = GraphedTrainStep(model, RelativeL2Loss(size_average=True), opt, x, y)
+    return lambda: step(x, y)
+
+
 torch.manual_seed(0)
 m = FNO1d(1, 1, modes=16, width=64).to(dev).train()
 for B in (16, 256):
     x = torch.randn(B, 1, 1024, device=dev)
     ms = timed(train_step(m, x, torch.randn_like(x)))
-    print(f"cfg0 FNO1d 1024 train  B={B:4d}: {ms:8.3f} ms/step  {B / ms * 1e3:10.0f} samples/s", flush=True)
+    mg = timed(graphed(m, x, torch.randn_like(x)))
+    print(f"cfg0 FNO1d 1024 train  B={B:4d}: {ms:8.3f} ms/step  {B / ms * 1e3:10.0f} samples/s | hipGraph {mg:8.3f} ms/step "
+          f"{B / mg * 1e3:10.0f} samples/s", flush=True)
 m = FFNO1D(1, 1, width=128, n_layers=4, n_modes=64, factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False,
            dropout=0.0).to(dev).train()
 for B in (16, 256):
     x = torch.randn(B, 1, 512, device=dev)
     ms = timed(train_step(m, x, torch.randn_like(x)))
-    print(f"cfg1 FFNO1D 512 train  B={B:4d}: {ms:8.3f} ms/step  {B / ms * 1e3:10.0f} samples/s", flush=True)
+    mg = timed(graphed(m, x, torch.randn_like(x)))
+    print(f"cfg1 FFNO1D 512 train  B={B:4d}: {ms:8.3f} ms/step  {B / ms * 1e3:10.0f} samples/s | hipGraph {mg:8.3f} ms/step "
+          f"{B / mg * 1e3:10.0f} samples/s", flush=True)
 m = FNO2d(1, 1, modes1=12, modes2=12, width=32).to(dev).eval()
 for B in (4, 16):
     x = torch.randn(B, 1, 512, 512, device=dev)

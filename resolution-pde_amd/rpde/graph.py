@@ -1,0 +1,78 @@
+"""hipGraph capture of a whole training step (forward + loss + backward + optimizer).
+
+The 1-D configurations (FNO1d / FFNO1D at batch 16) run ~150-250 small kernels per step.  Captured once and
+replayed, the step costs one graph launch on the host.  Measured on MI355X (profiles/other_configs.py): no
+gain -- FNO1d 1024, B=16: 1.54 ms eager vs 1.71 ms replayed; FFNO1D 512, B=16: 2.10 vs 2.32 -- the step is bound
+by the GPU-side dispatch of the small kernels (~8 us each), not by host launches, so the lever for those
+configurations is fewer kernels, not graphs.  Kept as an option for hosts with slow Python / many ranks per
+socket.
+Everything the step does already is stream-ordered and allocation-free at the HIP level (workspaces come
+from torch's caching allocator, DFT plans are created on first use), so the capture needs no changes in the
+library -- only: plans and autotuned state must exist before capture (warm-up steps), the optimizer must be
+capturable, and nothing in the step may read a host-side random seed: FeedForward dropout draws its seed on
+the host, so a model with dropout > 0 in training mode is refused here (its mask would freeze).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+
+def _has_active_dropout(model: torch.nn.Module) -> bool:
+    for m in model.modules():
+        p = getattr(m, "dropout", None)
+        if isinstance(p, float) and p > 0.0 and m.training:
+            return True
+        if isinstance(m, torch.nn.Dropout) and m.p > 0.0 and m.training:
+            return True
+    return False
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(model, loss_fn, optimizer, x_example, y_example); loss = step(x, y)
+
+    x / y of later calls must have the example's shape and dtype (one graph per shape; build one instance per
+    resolution for multi-resolution training).  `after_backward` (e.g. FlatGradBucket.all_reduce_mean) runs
+    inside the captured region between backward and the optimizer step."""
+
+    def __init__(self, model, loss_fn, optimizer, x: torch.Tensor, y: torch.Tensor, warmup: int = 3,
+                 after_backward: Optional[Callable[[], None]] = None):
+        if not x.is_cuda:
+            raise ValueError("GraphedTrainStep needs HIP tensors")
+        if _has_active_dropout(model):
+            raise ValueError("GraphedTrainStep: dropout > 0 in training mode draws a host-side seed per step; "
+                             "a captured graph would replay one mask.  Use eager steps for this model.")
+        for group in optimizer.param_groups:
+            if "capturable" in group and not group["capturable"]:
+                raise ValueError("GraphedTrainStep: build the optimizer with capturable=True")
+        self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
+        self.after_backward = after_backward
+        self.x, self.y = x.clone(), y.clone()
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):      # creates DFT plans, sizes the allocator pools, primes optimizer state
+                self._eager()
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        torch.cuda.synchronize(x.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager()
+
+    def _eager(self) -> torch.Tensor:
+        self.optimizer.zero_grad(set_to_none=False)
+        loss = self.loss_fn(self.model(self.x), self.y)
+        loss.backward()
+        if self.after_backward is not None:
+            self.after_backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        if x.shape != self.x.shape or y.shape != self.y.shape:
+            raise ValueError(f"GraphedTrainStep was captured for {tuple(self.x.shape)} / {tuple(self.y.shape)}")
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        return self.loss

@@ -184,3 +184,41 @@ def test_skip_gradient_folded_into_spectral_backward(gpu_device, dims):
     b2, _ = layer(hh, residual=hh.detach() * 1.0)      # a different tensor object: plain route, skip not differentiated
     (b2.sum() + hh.sum()).backward()                   # d(residual)/dh = 1 added by hand
     assert float((hh.grad - g_fused).norm() / g_fused.norm()) < 1e-6
+
+
+def test_graphed_train_step_matches_eager(gpu_device):
+    """rpde.graph.GraphedTrainStep: the captured hipGraph replays the same step as eager execution."""
+    import copy
+    from models.fno import FNO1d
+    from rpde.graph import GraphedTrainStep
+    from utils.loss import RelativeL2Loss
+    torch.manual_seed(3)
+    m_e = FNO1d(1, 1, modes=8, width=16).to(gpu_device).train()
+    m_g = copy.deepcopy(m_e)
+    xs = [torch.randn(4, 1, 128, device=gpu_device) for _ in range(4)]
+    ys = [torch.randn(4, 1, 128, device=gpu_device) for _ in range(4)]
+    loss_fn = RelativeL2Loss(size_average=True)
+    o_e = torch.optim.AdamW(m_e.parameters(), lr=1e-3, capturable=True)
+    o_g = torch.optim.AdamW(m_g.parameters(), lr=1e-3, capturable=True)
+    warm = 2
+    for _ in range(warm):                                   # the graphed step warms up on its example batch
+        o_e.zero_grad(set_to_none=False)
+        loss_fn(m_e(xs[0]), ys[0]).backward()
+        o_e.step()
+    step = GraphedTrainStep(m_g, loss_fn, o_g, xs[0], ys[0], warmup=warm)
+    # capture itself executes nothing; both models are now `warm` steps in
+    for x, y in zip(xs, ys):
+        o_e.zero_grad(set_to_none=False)
+        le = loss_fn(m_e(x), y)
+        le.backward()
+        o_e.step()
+        lg = step(x, y)
+        assert abs(float(le.detach()) - float(lg)) <= 1e-6 * max(1.0, abs(float(le.detach())))
+    for pe, pg in zip(m_e.parameters(), m_g.parameters()):
+        a, b = torch.view_as_real(pe) if pe.is_complex() else pe, torch.view_as_real(pg) if pg.is_complex() else pg
+        assert float((a - b).norm() / (a.norm() + 1e-30)) < 1e-6
+    from models.ffno import FFNO2D
+    with pytest.raises(ValueError, match="dropout"):
+        md = FFNO2D(1, 1, width=8, n_layers=1, n_modes=4, dropout=0.1).to(gpu_device).train()
+        GraphedTrainStep(md, loss_fn, torch.optim.AdamW(md.parameters(), capturable=True),
+                         torch.randn(2, 1, 16, 16, device=gpu_device), torch.randn(2, 1, 16, 16, device=gpu_device))
