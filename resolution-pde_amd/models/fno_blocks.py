@@ -27,7 +27,7 @@ class _FNOBlock(nn.Module):
     def pre_activation(self, x, act_in="identity"):
         """spectral_conv(act_in(x)) + bypass_conv(act_in(x)) (bias included)"""
         spec = self.spectral_conv(x, act_in)
-        return ops.conv1x1(x, self.bypass_conv.weight, self.bypass_conv.bias, act_in, acc=spec)
+        return ops.conv1x1(x, self.bypass_conv.weight, self.bypass_conv.bias, act_in, acc=spec, acc_owned=True)
 
     def forward(self, x):
         return ops.activation(self.pre_activation(x), act_name(self.activation))

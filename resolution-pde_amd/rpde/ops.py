@@ -352,8 +352,10 @@ def spectral2d(x, w1, w2, act_in: str = "identity"):
 
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, act_in: int, acc):
-        """out = (acc +) W . act(x) + b ; x [B,Cin,*S] channels-first, w [Cout,Cin,1(,1)]"""
+    def forward(ctx, x, w, b, act_in: int, acc, acc_owned: bool = False):
+        """out = (acc +) W . act(x) + b ; x [B,Cin,*S] channels-first, w [Cout,Cin,1(,1)]
+        acc_owned: the caller hands over `acc` (a temporary it will not read again): accumulate in place even
+        when autograd cannot tell (no_grad / eval, where every tensor is a leaf)"""
         lib = load()
         x = _f32c(x)
         B, Ci = x.shape[0], x.shape[1]
@@ -362,7 +364,7 @@ class _Conv1x1(torch.autograd.Function):
         w2 = _f32c(w).reshape(Co, Ci)
         b = _f32c(b) if b is not None else None
         if acc is not None:
-            if acc.dtype == torch.float32 and acc.is_contiguous() and not acc.is_leaf:
+            if acc.dtype == torch.float32 and acc.is_contiguous() and (not acc.is_leaf or (acc_owned and not acc.requires_grad)):
                 ctx.mark_dirty(acc)          # accumulate in place into the spectral branch's output
                 out = acc
             else:
@@ -388,11 +390,11 @@ class _Conv1x1(torch.autograd.Function):
         ws = workspace(nws, g.device)
         check(lib.rpde_conv1x1_bwd(ptr(x), ptr(w2), ptr(g), ptr(gx), ptr(gw), ptr(gb), B, Ci, Co, S, act_in, 0,
                                    ws.data_ptr(), nws, stream_ptr()), "conv1x1_bwd")
-        return gx, (gw.reshape(wshape) if gw is not None else None), gb, None, (g if has_acc else None)
+        return gx, (gw.reshape(wshape) if gw is not None else None), gb, None, (g if has_acc else None), None
 
 
-def conv1x1(x, w, b=None, act_in: str = "identity", acc=None):
-    return _Conv1x1.apply(x, w, b, ACT[act_in], acc)
+def conv1x1(x, w, b=None, act_in: str = "identity", acc=None, acc_owned: bool = False):
+    return _Conv1x1.apply(x, w, b, ACT[act_in], acc, acc_owned)
 
 
 class _Act(torch.autograd.Function):
