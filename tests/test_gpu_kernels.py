@@ -69,6 +69,31 @@ def test_gemm_layouts_and_edges(gpu_device, M, N, K, a_k, b_k):
     assert err < GEMM_TOL, err
 
 
+def test_gemm_fuzz_shapes_layouts_splits(gpu_device):
+    """120 seeded random problems: every layout, ragged and aligned extents (both the split-bf16 and the native
+    kernels get picked), batches, K-splits that are / are not multiples of 8 (both workgroup orders)."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for it in range(120):
+        aligned = rng.random() < 0.6
+        q = 4 if aligned else 1
+        M = int(rng.integers(1, 80)) * q
+        N = int(rng.integers(1, 80)) * q
+        K = int(rng.choice([32, 64, 96, 128, 256])) if (aligned and rng.random() < 0.7) else int(rng.integers(1, 300))
+        a_k, b_k = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        batch = int(rng.choice([1, 1, 2, 5]))
+        ksplit = int(rng.choice([1, 1, 1, 3, 8, 16]))
+        if ksplit > 1:
+            K = max(K, 64) * 4
+            err = _gemm(gpu_device, M, N, K, a_k, b_k, batch=batch, ksplit=ksplit, seed=it)
+        else:
+            err = _gemm(gpu_device, M, N, K, a_k, b_k, batch=batch, seed=it, bias_mode=int(rng.integers(0, 3)),
+                        accumulate=bool(rng.integers(0, 2)), alpha=float(rng.choice([1.0, 0.5, -2.0])))
+        worst = max(worst, err)
+        assert err < 4e-6, (it, M, N, K, a_k, b_k, batch, ksplit, err)
+    assert worst > 0.0
+
+
 def test_gemm_batched_bias_accumulate(gpu_device):
     assert _gemm(gpu_device, 130, 70, 50, 1, 0, batch=5, bias_mode=1, accumulate=True) < GEMM_TOL
     assert _gemm(gpu_device, 64, 200, 33, 1, 0, batch=3, bias_mode=2, alpha=0.5) < GEMM_TOL
