@@ -1,7 +1,9 @@
 """Shared body of main_1d.py / main_2d.py: compose config, build data, model,
 optimiser and scheduler, train, test, checkpoint -- the sequence of the
-reference's entry points (main_1d.py:34-309, main_2d.py:38-324) minus wandb,
-plotting and the HDF5 loaders (out of scope / row f4)."""
+reference's entry points (main_1d.py:34-309, main_2d.py:38-324) minus wandb and
+plotting.  Datasets: synthetic Markov pairs (default), or a file through the
+reference's `dataset_params` convention (conf/dataset/ns/ns_file.yaml ->
+dataloaders/ns_naive_markov.py)."""
 from __future__ import annotations
 
 import json
@@ -43,10 +45,17 @@ def run(dims: int, argv=None):
 
     seed = int(args.training.get("seed", 0))
     bs = int(args.training.batch_size)
-    train_set = markov_pairs(args.dataset.resolutions, dims, seed)
-    top = max(int(r) for r in dict(args.dataset.resolutions))
-    val_set = markov_pairs({top: int(args.dataset.n_val)}, dims, seed + 50000)
-    test_set = markov_pairs({top: int(args.dataset.n_test)}, dims, seed + 60000)
+    x_normalizer = y_normalizer = None
+    if args.dataset.get("dataset_params"):                     # reference main_2d.py:72-73
+        data_ = instantiate(args.dataset.dataset_params)
+        train_set, val_set, test_set = data_[:3]
+        if len(data_) >= 5:
+            x_normalizer, y_normalizer = data_[3], data_[4]
+    else:
+        train_set = markov_pairs(args.dataset.resolutions, dims, seed)
+        top = max(int(r) for r in dict(args.dataset.resolutions))
+        val_set = markov_pairs({top: int(args.dataset.n_val)}, dims, seed + 50000)
+        test_set = markov_pairs({top: int(args.dataset.n_test)}, dims, seed + 60000)
     mk = lambda ds, shuffle: ResolutionGroupedDataLoader(ds, bs, shuffle=shuffle, seed=seed, rank=rank,  # noqa: E731
                                                          world_size=world, verbose=rank == 0)
     train_loader, val_loader, test_loader = mk(train_set, True), mk(val_set, False), mk(test_set, False)
@@ -71,11 +80,11 @@ def run(dims: int, argv=None):
         print(json.dumps({"model": args.model["_target_"], "params": n_params, "world": world,
                           "train_batches": len(train_loader), "choices": args["_choices_"]}), flush=True)
     t0 = time.time()
-    loss_hist, val_hist = train(model, train_loader, val_loader, optimizer, scheduler,
+    loss_hist, val_hist = train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=y_normalizer,
                                 use_normalizer=bool(args.training.use_normalizer), epochs=int(args.training.epochs),
                                 device=device)
     torch.cuda.synchronize()
-    test_l2 = evaluate(model, test_loader, device=device)
+    test_l2 = evaluate(model, test_loader, y_normalizer=y_normalizer, device=device)
     if rank == 0:
         print(json.dumps({"train_seconds": round(time.time() - t0, 3), "final_train_loss": loss_hist[-1],
                           "final_val_loss": val_hist[-1], "test_rel_l2": test_l2}), flush=True)

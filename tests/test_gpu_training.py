@@ -222,3 +222,25 @@ def test_graphed_train_step_matches_eager(gpu_device):
         md = FFNO2D(1, 1, width=8, n_layers=1, n_modes=4, dropout=0.1).to(gpu_device).train()
         GraphedTrainStep(md, loss_fn, torch.optim.AdamW(md.parameters(), capturable=True),
                          torch.randn(2, 1, 16, 16, device=gpu_device), torch.randn(2, 1, 16, 16, device=gpu_device))
+
+
+def test_main_2d_on_a_file_dataset_with_normalisers(gpu_device, tmp_path, capsys):
+    """dataset=ns/ns_file: the reference's dataset_params convention -> dataloaders/ns_naive_markov.py (row f4),
+    unit-Gaussian normalisers decoded inside the loss, on a small synthetic .npz of smooth advected fields."""
+    import numpy as np
+    from rpde.entry import run
+    from utils.synthetic import advance, random_fields
+    u0 = random_fields(24, 32, 2, seed=3)                       # [24,1,32,32]
+    frames = [u0]
+    for _ in range(7):
+        frames.append(advance(frames[-1], 2))
+    u = torch.cat(frames, dim=1).numpy().astype(np.float32) * 3.0 + 1.5          # [N,T,H,W], not unit scale
+    np.savez(tmp_path / "ns_32_synth.npz", u=u)
+    l2 = run(2, ["model=ffno_2d/ffno_2d", "dataset=ns/ns_file", "dataset.dataset_params.filename=ns_32_synth.npz",
+                 f"dataset.dataset_params.saved_folder={tmp_path}", "model.width=16", "model.n_layers=2",
+                 "model.n_modes=8", "model.factor=2", "training.epochs=6", "training.batch_size=8",
+                 "training.learning_rate=0.003", "training.use_normalizer=true", f"checkpoint_dir={tmp_path}"])
+    out = capsys.readouterr().out
+    import json
+    e0 = json.loads([ln for ln in out.splitlines() if '"epoch": 0' in ln][0])
+    assert l2 < 1.0 and l2 < e0["val_loss"], (l2, e0)
