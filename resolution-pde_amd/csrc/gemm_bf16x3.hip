@@ -23,6 +23,8 @@
 // stored derivative / accumulate / per-tile column sums).
 #include "gemm_kernel.h"
 
+#include <stdlib.h>
+
 namespace rpde {
 
 // RPDE_STAMPS (debug builds only: rpde/build.py --stamps): wave 0 of 64 mid-launch workgroups records
@@ -74,9 +76,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 //    ds_read_b64_tr_b16 (each group of 16 lanes fetches a 4(k) x 16(row) block and receives it column
 //    major), so the store side stays a plain vector write.  8-byte chunks are XOR-swizzled so that the four
 //    k-rows a half-wave reads land on different banks.
-template <int ROWS, bool KMAJOR>
+template <int ROWS, bool KMAJOR, int NT = NTHREADS>
 struct XTile {
-  static constexpr int NV = ROWS * XBK / 4 / NTHREADS;     // float4 per thread (ROWS/32)
+  static constexpr int NV = ROWS * XBK / 4 / NT;           // float4 per thread
   static constexpr int IMG_BYTES = ROWS * 64;              // one bf16 image
   static constexpr int CPR = ROWS / 4;                     // x-major: 8-byte chunks per k-row
   static_assert(NV >= 1 && (ROWS == 64 || ROWS == 128), "unsupported tile");
@@ -87,7 +89,7 @@ struct XTile {
 
   // vector i of this thread covers: k-major: row rr, k = kk..kk+3;  x-major: rows rr..rr+3 at k = kk
   __device__ __forceinline__ static void coords(int tid, int i, int& rr, int& kk) {
-    const int v = tid + i * NTHREADS;
+    const int v = tid + i * NT;
     if (KMAJOR) { rr = v >> 3; kk = (v & 7) << 2; }
     else { kk = v / CPR; rr = (v % CPR) << 2; }
   }
@@ -165,17 +167,17 @@ struct XTile {
 
 // one stage of a pre-split operand: NBI 16-byte chunks per image per thread, straight copies
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int NBI>
+template <int NBI, int NT>
 __device__ __forceinline__ void bimg_load(u32x4 (&r)[3 * NBI], const char* __restrict__ p, long img_stride) {
 #pragma unroll
   for (int i = 0; i < 3 * NBI; ++i)
-    r[i] = *reinterpret_cast<const u32x4*>(p + (i / NBI) * img_stride + (i % NBI) * (NTHREADS * 16));
+    r[i] = *reinterpret_cast<const u32x4*>(p + (i / NBI) * img_stride + (i % NBI) * (NT * 16));
 }
-template <int NBI>
+template <int NBI, int NT>
 __device__ __forceinline__ void bimg_store(char* __restrict__ lds, const u32x4 (&r)[3 * NBI], int img_bytes) {
 #pragma unroll
   for (int i = 0; i < 3 * NBI; ++i)
-    *reinterpret_cast<u32x4*>(lds + (i / NBI) * img_bytes + (i % NBI) * (NTHREADS * 16)) = r[i];
+    *reinterpret_cast<u32x4*>(lds + (i / NBI) * img_bytes + (i % NBI) * (NT * 16)) = r[i];
 }
 
 // BIMG: the B operand arrives pre-split (rpde_split_weights: [K/32][3][Npad][32] bf16 images whose rows are
@@ -186,12 +188,13 @@ __device__ __forceinline__ void bimg_store(char* __restrict__ lds, const u32x4 (
 // AIMG: the same for the A operand (the DFT tables of the spectral layers, split once per plan); with it
 // K may have a tail (the images are zero-padded to a multiple of 32) as long as B is x-major.
 template <int WM, int WN, int TM, int TN, bool AK, bool BKM, bool BIMG = false, bool AIMG = false>
-__global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g) {
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x3_kernel(const GemmK g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  static_assert(WM * WN == 4, "four waves per workgroup");
+  constexpr int NT = 64 * WM * WN;          // 4 waves (3 workgroups per CU) or 8 waves (2 per CU = 4 waves per SIMD)
+  static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
   static_assert(!(AIMG && BIMG), "one pre-split operand per product");
-  using TA = XTile<BM, AK || AIMG>;
-  using TB = XTile<BN, BKM>;
+  using TA = XTile<BM, AK || AIMG, NT>;
+  using TB = XTile<BN, BKM, NT>;
   constexpr int SMEM_BYTES = 3 * (TA::IMG_BYTES + TB::IMG_BYTES);
   constexpr int SMEM_FLOATS = SMEM_BYTES / 4;
   constexpr int EP = (BM * BN + SMEM_FLOATS - 1) / SMEM_FLOATS;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  constexpr int NBI = BIMG ? BN * 4 / NTHREADS : (AIMG ? BM * 4 / NTHREADS : 1);   // 16-byte chunks per image per thread
+  constexpr int NBI = BIMG ? BN * 4 / NT : (AIMG ? BM * 4 / NT : 1);   // 16-byte chunks per image per thread
   static_assert(!BIMG || (BKM && NBI >= 1), "pre-split B is k-major");
   constexpr bool IMG = AIMG || BIMG;
   int oa[TA::NV], ob[TB::NV];
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   float4 ra[TA::NV], rb[TB::NV];
   if (nkt > 0) {
     if (!AIMG) TA::load(ra, at, oa);
-    if (IMG) bimg_load<NBI>(rbi, bimg, (long)g.npad * 64);
+    if (IMG) bimg_load<NBI, NT>(rbi, bimg, (long)g.npad * 64);
     if (!BIMG) {
       if (tail && nkt == 1) TB::load_tail(rb, bt, ob, (int)g.ldb, tail, tid); else TB::load(rb, bt, ob);
     }
@@ -271,15 +274,15 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   //  a resident wave, and three workgroups per CU already cover the load latency)
   STAMP(1);
   for (int kt = 0; kt < nkt; ++kt) {
-    if (AIMG) bimg_store<NBI>(As + tid * 16, rbi, TA::IMG_BYTES); else TA::store(As, ra, tid);
-    if (BIMG) bimg_store<NBI>(Bs + tid * 16, rbi, TB::IMG_BYTES); else TB::store(Bs, rb, tid);
+    if (AIMG) bimg_store<NBI, NT>(As + tid * 16, rbi, TA::IMG_BYTES); else TA::store(As, ra, tid);
+    if (BIMG) bimg_store<NBI, NT>(Bs + tid * 16, rbi, TB::IMG_BYTES); else TB::store(Bs, rb, tid);
     if (kt < 8) STAMP(2 + 3 * kt);
     __syncthreads();
     if (kt < 8) STAMP(3 + 3 * kt);
     if (kt + 1 < nkt) {
       at += astep; bt += bstep; bimg += bimg_step;
       if (!AIMG) TA::load(ra, at, oa);
-      if (IMG) bimg_load<NBI>(rbi, bimg, (long)g.npad * 64);
+      if (IMG) bimg_load<NBI, NT>(rbi, bimg, (long)g.npad * 64);
       if (!BIMG) {
         if (tail && kt + 2 == nkt) TB::load_tail(rb, bt, ob, (int)g.ldb, tail, tid); else TB::load(rb, bt, ob);
       }
@@ -338,8 +341,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
   float* __restrict__ cs = reinterpret_cast<float*>(smem_raw);
   constexpr int SLAB = BM / EP;
   constexpr int VPR = BN / 4;
-  constexpr int NV4 = SLAB * BN / 4 / NTHREADS;
-  constexpr int RSTEP = NTHREADS / VPR;
+  constexpr int NV4 = SLAB * BN / 4 / NT;
+  constexpr int RSTEP = NT / VPR;
   static_assert(NV4 >= 1, "epilogue slab too small");
   const int c4 = (tid % VPR) * 4, row0 = tid / VPR;
   const int gn = n0 + c4;
@@ -471,13 +474,13 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_bf16x3_kernel(const GemmK g)
 
 template <int WM, int WN, int TM, int TN>
 static void launch_x3_layout(const GemmK& g, bool ak, bool bk, dim3 grid, hipStream_t st) {
-  if (g.a_img && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true, false, true>), grid, dim3(NTHREADS), 0, st, g);
-  else if (g.a_img) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, false, false, true>), grid, dim3(NTHREADS), 0, st, g);
-  else if (ak && bk && g.Bimg) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(NTHREADS), 0, st, g);
-  else if (ak && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true>), grid, dim3(NTHREADS), 0, st, g);
-  else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, false>), grid, dim3(NTHREADS), 0, st, g);
-  else if (!ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, false>), grid, dim3(NTHREADS), 0, st, g);
-  else hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, true>), grid, dim3(NTHREADS), 0, st, g);
+  if (g.a_img && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true, false, true>), grid, dim3(64 * WM * WN), 0, st, g);
+  else if (g.a_img) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, false, false, true>), grid, dim3(64 * WM * WN), 0, st, g);
+  else if (ak && bk && g.Bimg) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(64 * WM * WN), 0, st, g);
+  else if (ak && bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, true>), grid, dim3(64 * WM * WN), 0, st, g);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, true, false>), grid, dim3(64 * WM * WN), 0, st, g);
+  else if (!ak && !bk) hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, false>), grid, dim3(64 * WM * WN), 0, st, g);
+  else hipLaunchKernelGGL((gemm_bf16x3_kernel<WM, WN, TM, TN, false, true>), grid, dim3(64 * WM * WN), 0, st, g);
 }
 
 // fp32 weights [N,K] (k-major, ld) or [K,N] (x-major) -> [K/32][3][Npad][32] bf16 images, 16-byte chunks of
@@ -520,6 +523,8 @@ int split_weights(const float* w, int kmajor, long ld, int N, int K, void* out, 
 bool bf16x3_supports(int bm, int bn) { return (bm == 128 || bm == 64) && (bn == 128 || bn == 64); }
 
 int launch_bf16x3(const GemmK& g, int bm, int bn, bool ak, bool bk, dim3 grid, hipStream_t st) {
+  // (an eight-wave 128x128 variant -- gemm_bf16x3_kernel<2, 4, 2, 1, ...>, 98 VGPRs, 4 waves per SIMD -- is
+  //  correct but measured 6 % slower on the FeedForward forward GEMM: the kernel is not latency bound)
   if (bm == 128 && bn == 128) launch_x3_layout<2, 2, 2, 2>(g, ak, bk, grid, st);
   else if (bm == 128 && bn == 64) launch_x3_layout<4, 1, 1, 2>(g, ak, bk, grid, st);
   else if (bm == 64 && bn == 128) launch_x3_layout<1, 4, 2, 1>(g, ak, bk, grid, st);
