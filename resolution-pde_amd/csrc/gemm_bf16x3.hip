@@ -287,6 +287,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x
         if (tail && kt + 2 == nkt) TB::load_tail(rb, bt, ob, (int)g.ldb, tail, tid); else TB::load(rb, bt, ob);
       }
     }
+#ifndef RPDE_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(1);       // MFMA phase first: the other waves' vector work fits in its issue gaps
+#endif
 #pragma unroll
     for (int s = 0; s < XBK / 16; ++s) {
       // two rounds so that only 8 fragments (32 VGPRs) are live at a time: (hi, mid) of both operands first,
@@ -330,6 +333,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifndef RPDE_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
     if (kt < 8) STAMP(4 + 3 * kt);
   }
