@@ -315,7 +315,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], c, 0, 0, 0);
           acc[i][j] = c;
         }
-      __builtin_amdgcn_sched_barrier(0);
+      // (fencing the rounds pays only where the fragment reads are the transposing ones: weight gradient +3 %,
+      //  k-major kernels -2 %; same-box A/B)
+      if constexpr (!AK && !BKM && !AIMG) __builtin_amdgcn_sched_barrier(0);
       bf16x8 a2[TM], b2[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a2[i] = TA::frag(As, fa[i], 2, (wm * TM + i) * 32 + l31, lh, s);
@@ -331,7 +333,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], c, 0, 0, 0);
           acc[i][j] = c;
         }
-      __builtin_amdgcn_sched_barrier(0);
+      // (fencing the rounds pays only where the fragment reads are the transposing ones: weight gradient +3 %,
+      //  k-major kernels -2 %; same-box A/B)
+      if constexpr (!AK && !BKM && !AIMG) __builtin_amdgcn_sched_barrier(0);
     }
 #ifndef RPDE_NO_SETPRIO
     __builtin_amdgcn_s_setprio(0);
