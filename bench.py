@@ -45,18 +45,13 @@ PEAK_BF16_MFMA_TF = 2500.0    # dense bf16 matrix peak; the split-bf16 fp32 GEMM
 
 def synth_batch(b, res, seed, device):
     """periodic Gaussian random fields, spectrum (4 pi^2 |k|^2 + tau^2)^(-alpha/2), alpha=2.5, tau=7
-    (data_generation/random_fields.py parameters), standardised to mean 0 / std 1"""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    out = []
-    for _ in range(2):
-        white = torch.randn(b, 1, res, res, generator=g)
-        kx = torch.fft.fftfreq(res, 1.0 / res)[:, None]
-        ky = torch.fft.rfftfreq(res, 1.0 / res)[None, :]
-        filt = (4 * torch.pi ** 2 * (kx ** 2 + ky ** 2) + 49.0) ** (-1.25)
-        f = torch.fft.irfft2(torch.fft.rfft2(white) * filt, s=(res, res))
-        f = (f - f.mean()) / f.std()
-        out.append(f.to(device))
-    return out
+    (data_generation/random_fields.py parameters), standardised to mean 0 / std 1; the target is the input
+    advanced by a fixed linear spectral filter (utils/synthetic.py: diffusion + translation), so the
+    relative-L2 training loss is meaningful and decreases"""
+    from utils.synthetic import advance, random_fields
+    x = random_fields(b, res, 2, seed)
+    y = advance(x, 2)
+    return [x.to(device), y.to(device)]
 
 
 def _time_gemm(desc, iters):
@@ -173,14 +168,12 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("RPDE_CPU_THREADS", "64"))))
 
 
-def cpu_baseline(batch=2, warm=1, timed=2):
-    """the CPU oracle (pinned restatement of the reference) doing the same training step"""
+def _cpu_steps(batch, warm, timed, threads):
     from models.ffno import FFNO2D
     from oracle import reference_path as R
     torch.manual_seed(0)
     sd = {k: v.clone() for k, v in FFNO2D(**CFG3).state_dict().items()}
-    cores = host_cores()
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     params = R.make_params(sd)
     opt = torch.optim.AdamW(list(params.values()), lr=1e-3)
     x, y = synth_batch(batch, RES, 99, "cpu")
@@ -188,13 +181,27 @@ def cpu_baseline(batch=2, warm=1, timed=2):
                                          CFG3["layer_norm"], CFG3["dropout"], training=True)
     for _ in range(warm):
         R.train_step(fwd, params, opt, x, y)
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(timed):
+        t0 = time.perf_counter()
         R.train_step(fwd, params, opt, x, y)
-    dt = (time.perf_counter() - t0) / timed
-    return {"value": round(batch / dt, 4), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{timed} timed + {warm} warm-up training steps (fwd + rel-L2 + bwd + AdamW, dropout 0.1) of the "
-                      f"CPU oracle at batch {batch}, 256^2, fp32, {torch.get_num_threads()} threads"}
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], torch.get_num_threads()
+
+
+def cpu_baseline(batch=4, warm=2, timed=5):
+    """the CPU oracle (pinned restatement of the reference) doing the same training step on the host cores
+    (2 warm + 5 timed, median; plus one 1-thread step for a per-core figure)"""
+    cores = host_cores()
+    med, used = _cpu_steps(batch, warm, timed, cores)
+    one, _ = _cpu_steps(1, 0, 1, 1)
+    torch.set_num_threads(cores)
+    return {"value": round(batch / med, 4), "unit": "samples/s", "cores": used, "kind": "port",
+            "sample": f"median of {timed} timed (+{warm} warm-up) training steps (fwd + rel-L2 + bwd + AdamW, dropout 0.1) "
+                      f"of the CPU oracle at batch {batch}, 256^2, fp32, {used} threads",
+            "one_thread": {"value": round(1.0 / one, 4), "unit": "samples/s", "cores": 1,
+                           "sample": "1 training step at batch 1, 1 thread, no warm-up"}}
 
 
 def parity_check(device):
@@ -230,9 +237,23 @@ def main():
                     help="profiling aid: stop after the timed training steps (no kernel microbenchmarks, no parity leg)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # --gpus N without a launcher: this (GPU-free) parent starts the N ranks itself and returns their exit code
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        from rpde.launch import spawn_ranks
+        raise SystemExit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values", file=sys.stderr)
+        raise SystemExit(2)
+    if os.environ.get("RPDE_BENCH_DRYRUN") == "1":
+        # launcher plumbing test (tests/test_bench_launcher_cpu.py): no GPU, no process group
+        print(json.dumps({"dryrun": True, "rank": rank, "local_rank": local, "world": world,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+        raise SystemExit(int(os.environ.get("RPDE_BENCH_FAIL_CODE", "3"))
+                         if os.environ.get("RPDE_BENCH_FAIL_RANK") == str(rank) else 0)
     # rehearsal aid: RPDE_DIST_BACKEND=gloo RPDE_SHARE_GPU=1 runs all ranks on cuda:0 (1-GPU box)
     backend = os.environ.get("RPDE_DIST_BACKEND", "nccl")
     if os.environ.get("RPDE_SHARE_GPU") == "1":
@@ -257,28 +278,35 @@ def main():
     B = args.batch
     x, y = synth_batch(B, RES, 1234 + rank, device)
     torch.manual_seed(100 + rank)              # dropout seeds differ per rank
-    loss_sum = torch.zeros((), device=device)
+    losses = torch.zeros(args.warmup + args.steps, device=device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ar_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step():
+    def step(i, timed=-1):
         bucket.zero()
         loss = loss_fn(model(x), y)
         loss.backward()
+        if world > 1 and timed >= 0:
+            ar_ev[timed][0].record()
         bucket.all_reduce_mean()
+        if world > 1 and timed >= 0:
+            ar_ev[timed][1].record()
         opt.step()
-        loss_sum.add_(loss.detach())           # device-side accumulation, no per-step host sync
+        losses[i].copy_(loss.detach())         # device-side bookkeeping, no per-step host sync
 
     log(f"model + data ready (B={B}/gpu, world={world})")
     for i in range(args.warmup):
-        step()
+        step(i)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
-    first_loss = None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    ev[0].record()
+    for i in range(args.steps):
+        step(args.warmup + i, i)
+        ev[i + 1].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -287,8 +315,11 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    mean_loss = float(loss_sum.item()) / max(1, args.steps + args.warmup)
-    log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
+    per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]       # noqa: E731
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_ev) / len(ar_ev) if world > 1 else 0.0
+    lh = losses.cpu().tolist()
+    log(f"timed region: {elapsed:.3f}s for {args.steps} steps; rel-L2 {lh[0]:.4f} -> {lh[-1]:.4f}")
 
     if rank == 0 and args.steps_only:
         print(json.dumps({"steps_only": True, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -318,7 +349,10 @@ def main():
                                    "(BASELINE configs[2])",
                        "batch_per_gpu": B, "global_batch": B * world, "grid": [RES, RES], "optimizer": "AdamW lr=1e-3",
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_bucket_bytes": bucket.nbytes,
-                       "mean_train_rel_l2": round(mean_loss, 6)},
+                       "allreduce_ms_per_step": round(ar_ms, 4),
+                       "step_ms_p10_p50_p90": [round(pct(0.1), 3), round(pct(0.5), 3), round(pct(0.9), 3)],
+                       "train_rel_l2_first_last": [round(lh[0], 6), round(lh[-1], 6)],
+                       "target": "input advanced by a fixed spectral filter (utils/synthetic.py:advance)"},
             # fp32 in/out/accumulate; products on the bf16 matrix pipe by exact 3-way splitting (6 MFMA terms):
             # compute roof 2500/6 = 417 TF(fp32-equivalent), arithmetic intensity 43 flop/B < ridge 52 -> HBM bound
             "roofline": {"kernel": "gemm split-bf16 NT [P,256]x[256,256]+bias -> h=gelu(dropout(z)), d=gelu'*scale "

@@ -1,0 +1,66 @@
+"""One process per GPU without torchrun: start N copies of a script with the
+torch.distributed environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), wait
+for them and hand back the worst exit code.
+
+The parent never touches the GPU (no HIP call, no ``torch.cuda`` query), so the
+children are ordinary fresh processes; rank 0 inherits stdout and prints the
+result line.  Counterpart of the reference's single-process
+``nn.DataParallel`` set-up (main_2d.py:89-94,147-149), done the
+one-process-per-GPU way.
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+import time
+from typing import List, Optional, Sequence
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def rank_env(rank: int, world: int, port: int, base: Optional[dict] = None) -> dict:
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    return env
+
+
+def spawn_ranks(script: str, argv: Sequence[str], world: int, poll_s: float = 0.2) -> int:
+    """run ``python script *argv`` as ranks 0..world-1; returns 0 when every rank
+    exited 0, else the first non-zero exit code seen (the other ranks are then
+    terminated by PID -- a rank that died would leave them waiting in a collective)"""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    port = free_port()
+    procs: List[subprocess.Popen] = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=rank_env(r, world, port)))
+    rc = 0
+    alive = set(range(world))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for o in sorted(alive):
+                    procs[o].terminate()
+        if alive:
+            time.sleep(poll_s)
+    if rc != 0:
+        deadline = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
