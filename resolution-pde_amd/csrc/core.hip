@@ -2,6 +2,7 @@
 // tables built on device in double precision, cached per device).
 #include "rpde_internal.h"
 #include "plan.h"
+#include "fused_spectral.h"
 
 #include <stdarg.h>
 #include <map>
@@ -138,6 +139,7 @@ static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, i
       RPDE_TRY(split_weights(p->fs, 0, m2, m2, n, p->img[IMG_FST], st));
       RPDE_TRY(split_weights(p->fs, 1, m2, n, m2, p->img[IMG_FS], st));
       RPDE_TRY(split_weights(p->fa, 0, p->ldn, n, m2, p->img[IMG_FAT], st));
+      if (n % 32 == 0 && n <= 256 && m2 <= 48) RPDE_TRY(h2_build_tables(p, st));
     }
   } else {
     if (bot < 0) bot = modes;
@@ -197,6 +199,10 @@ int rpde_plan_destroy(rpde_plan* p) {
   if (p->fa) (void)hipFree(p->fa);
   if (p->fs) (void)hipFree(p->fs);
   for (int i = 0; i < 4; ++i) if (p->img[i]) (void)hipFree(p->img[i]);
+  for (int i = 0; i < 2; ++i) {
+    if (p->h2_ana[i]) (void)hipFree(p->h2_ana[i]);
+    if (p->h2_syn[i]) (void)hipFree(p->h2_syn[i]);
+  }
   delete p;
   return RPDE_OK;
 }

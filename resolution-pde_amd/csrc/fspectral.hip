@@ -15,6 +15,7 @@
 #include "rpde_internal.h"
 #include "plan.h"
 #include "pointwise.h"
+#include "fused_spectral.h"
 
 namespace rpde {
 
@@ -168,6 +169,99 @@ static int axis_bwd(const Axis& ax, const float* g, const float* spec_in, const 
   return RPDE_OK;
 }
 
+// ---- fused 2-D path (fused_spectral.hip): one analysis launch for both axes, mode mix on the small spectra,
+// ---- one synthesis launch that writes the field once
+static size_t fused2d_ws(const Axis& ay, const Axis& ax, int C, bool backward) {
+  const size_t spy = arena_bytes(spec_floats(ay, C)), spx = arena_bytes(spec_floats(ax, C));
+  const size_t wblk = arena_bytes((size_t)ay.keff * 4 * C * C);
+  const size_t img = arena_bytes(fused2d_img_bytes(ay.rows, 2 * ay.kp) / 4) + arena_bytes(fused2d_img_bytes(ax.rows, 2 * ax.kp) / 4);
+  const size_t inv = arena_bytes(ay.rows) + arena_bytes(ax.rows);
+  size_t n = wblk + (spy > spx ? spy : spx) + img + inv;
+  if (backward) {
+    const int Sy = split_for(ay.rows, wgrad_tiles(C) * ay.keff), Sx = split_for(ax.rows, wgrad_tiles(C) * ax.keff);
+    const size_t sl = arena_bytes((size_t)(Sy > Sx ? Sy : Sx) * ay.keff * 4 * C * C);
+    n += spy + spx + sl;
+  }
+  return n;
+}
+
+static int fused2d_fwd(const Axis& ay, const Axis& ax, const float* x, const float* w_y, const float* w_x, float* out,
+                       float* spec_y, float* spec_x, int B, int M, int N, int C, int K, int mode, Arena& ar, hipStream_t st) {
+  RPDE_TRY(fused2d_analysis(x, spec_y, spec_x, ay.plan, ax.plan, 0, B, M, N, st));
+  float* wblk = ar.take((size_t)ay.keff * 4 * C * C);
+  const size_t sy = spec_floats(ay, C), sx = spec_floats(ax, C);
+  float* mixed = ar.take(sy > sx ? sy : sx);
+  void* imgy = ar.take(fused2d_img_bytes(ay.rows, 2 * ay.kp) / 4);
+  void* imgx = ar.take(fused2d_img_bytes(ax.rows, 2 * ax.kp) / 4);
+  float* invy = ar.take(ay.rows);
+  float* invx = ar.take(ax.rows);
+  if (!ar.ok()) { set_error("fspectral2d: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  const Axis* axes[2] = {&ay, &ax};
+  const float* ws_[2] = {w_y, w_x};
+  float* specs[2] = {spec_y, spec_x};
+  void* imgs[2] = {imgy, imgx};
+  float* invs[2] = {invy, invx};
+  for (int a = 0; a < 2; ++a) {
+    const Axis& A = *axes[a];
+    const float* syn_in = specs[a];
+    if (mode == RPDE_MODE_FULL) {
+      RPDE_TRY(pack_mix_weights(ws_[a], wblk, C, C, K, A.keff, st));
+      if (A.kp != A.keff) RPDE_HIP(hipMemsetAsync(mixed, 0, spec_floats(A, C) * sizeof(float), st));
+      RPDE_TRY(mode_mix(A, specs[a], wblk, mixed, C, false, st));
+      syn_in = mixed;
+    }
+    RPDE_TRY(fused2d_split(syn_in, imgs[a], invs[a], A.rows, 2 * A.kp, st));
+  }
+  return fused2d_synthesis(imgy, imgx, invy, invx, ay.plan, ax.plan, 0, out, nullptr, B, M, N, st);
+}
+
+static int fused2d_bwd(const Axis& ay, const Axis& ax, const float* g, const float* spec_y, const float* spec_x,
+                       const float* w_y, const float* w_x, float* gx, float* gwy, float* gwx, const float* skip, int B, int M,
+                       int N, int C, int K, int mode, Arena& ar, hipStream_t st) {
+  float* gsy = ar.take(spec_floats(ay, C));
+  float* gsx = ar.take(spec_floats(ax, C));
+  float* wblk = ar.take((size_t)ay.keff * 4 * C * C);
+  const size_t sy = spec_floats(ay, C), sx = spec_floats(ax, C);
+  float* dsp = ar.take(sy > sx ? sy : sx);
+  void* imgy = ar.take(fused2d_img_bytes(ay.rows, 2 * ay.kp) / 4);
+  void* imgx = ar.take(fused2d_img_bytes(ax.rows, 2 * ax.kp) / 4);
+  float* invy = ar.take(ay.rows);
+  float* invx = ar.take(ax.rows);
+  const int Sy = split_for(ay.rows, wgrad_tiles(C) * ay.keff), Sx = split_for(ax.rows, wgrad_tiles(C) * ax.keff);
+  float* slabs = ar.take((size_t)(Sy > Sx ? Sy : Sx) * ay.keff * 4 * C * C);
+  if (!ar.ok()) { set_error("fspectral2d: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  RPDE_TRY(fused2d_analysis(g, gsy, gsx, ay.plan, ax.plan, 1, B, M, N, st));
+  const Axis* axes[2] = {&ay, &ax};
+  const float* ws_[2] = {w_y, w_x};
+  const float* specs[2] = {spec_y, spec_x};
+  float* gspecs[2] = {gsy, gsx};
+  float* gws[2] = {gwy, gwx};
+  void* imgs[2] = {imgy, imgx};
+  float* invs[2] = {invy, invx};
+  const int Ss[2] = {Sy, Sx};
+  for (int a = 0; a < 2; ++a) {
+    const Axis& A = *axes[a];
+    const float* dspec = gspecs[a];
+    if (mode == RPDE_MODE_FULL) {
+      if (gws[a]) {
+        RPDE_TRY(mode_mix_wgrad(A, specs[a], gspecs[a], slabs, C, Ss[a], st));
+        RPDE_TRY(unpack_mix_grad(slabs, gws[a], C, C, K, A.keff, Ss[a], (long)A.keff * 4 * C * C, st));
+      }
+      if (gx) {
+        RPDE_TRY(pack_mix_weights(ws_[a], wblk, C, C, K, A.keff, st));
+        if (A.kp != A.keff) RPDE_HIP(hipMemsetAsync(dsp, 0, spec_floats(A, C) * sizeof(float), st));
+        RPDE_TRY(mode_mix(A, gspecs[a], wblk, dsp, C, true, st));
+        dspec = dsp;
+      }
+    } else if (gws[a]) {
+      RPDE_HIP(hipMemsetAsync(gws[a], 0, sizeof(float) * 2 * (size_t)C * C * K, st));
+    }
+    if (gx) RPDE_TRY(fused2d_split(dspec, imgs[a], invs[a], A.rows, 2 * A.kp, st));
+  }
+  if (gx) RPDE_TRY(fused2d_synthesis(imgy, imgx, invy, invx, ay.plan, ax.plan, 1, gx, skip, B, M, N, st));
+  return RPDE_OK;
+}
+
 }  // namespace rpde
 
 using namespace rpde;
@@ -214,7 +308,9 @@ size_t rpde_fspectral2d_ws_bytes(int B, int M, int N, int C, int K) {
   axis_dims(ay, N, K, B * M);
   axis_dims(ax, M, K, B * N);
   const size_t a = axis_ws_bytes(ay, C), b = axis_ws_bytes(ax, C);
-  return a > b ? a : b;   // the two axes run back to back and reuse the arena
+  size_t n = a > b ? a : b;   // the two axes run back to back and reuse the arena
+  if (fused2d_ok(M, N, C, ay.keff, ax.keff)) { const size_t f = fused2d_ws(ay, ax, C, true); if (f > n) n = f; }
+  return n;
 }
 size_t rpde_fspectral2d_spec_elems(int B, int M, int N, int C, int K, int axis) {
   Axis a;
@@ -233,6 +329,10 @@ int rpde_fspectral2d_fwd(const float* x, const float* w_y, const float* w_x, flo
   RPDE_TRY(make_axis(ay, N, K, RPDE_NORM_ORTHO, B * M, 1, (long)N * C, 0, C, st));
   // lines along x: one per (b,n), points N*C apart
   RPDE_TRY(make_axis(ax, M, K, RPDE_NORM_ORTHO, B * N, N, (long)M * N * C, C, (long)N * C, st));
+  if (fused2d_ok(M, N, C, ay.keff, ax.keff)) {
+    Arena ar(ws, ws_bytes);
+    return fused2d_fwd(ay, ax, x, w_y, w_x, out, spec_y, spec_x, B, M, N, C, K, mode, ar, st);
+  }
   {
     Arena ar(ws, ws_bytes);
     RPDE_TRY(axis_fwd(ax, x, w_x, K, out, spec_x, C, mode, 0, ar, st));
@@ -250,6 +350,11 @@ int rpde_fspectral2d_bwd(const float* grad_out, const float* spec_y, const float
   Axis ay, ax;
   RPDE_TRY(make_axis(ay, N, K, RPDE_NORM_ORTHO, B * M, 1, (long)N * C, 0, C, st));
   RPDE_TRY(make_axis(ax, M, K, RPDE_NORM_ORTHO, B * N, N, (long)M * N * C, C, (long)N * C, st));
+  if (fused2d_ok(M, N, C, ay.keff, ax.keff)) {
+    Arena ar(ws, ws_bytes);
+    return fused2d_bwd(ay, ax, grad_out, spec_y, spec_x, w_y, w_x, grad_x, grad_wy, grad_wx, grad_skip, B, M, N, C, K, mode,
+                       ar, st);
+  }
   {
     Arena ar(ws, ws_bytes);
     RPDE_TRY(axis_bwd(ax, grad_out, spec_x, w_x, K, grad_x, grad_wx, C, mode, 0, ar, st, grad_skip));

@@ -14,6 +14,10 @@ struct rpde_plan {
   // real, interleaved plans: the tables pre-split for the split-bf16 GEMM (gemm_bf16x3.hip), as A operands:
   // [IMG_FA] Fa (2kp x n), [IMG_FST] Fs^T (2kp x n), [IMG_FS] Fs (n x 2kp), [IMG_FAT] Fa^T (n x 2kp)
   void* img[4];
+  // real, interleaved plans with n % 32 == 0, n <= 256 and <= 24 padded modes: the tables as ready f16 hi/lo MFMA
+  // fragments for the fused kernels (fused_spectral.hip): [0] forward operand (Fa / Fs), [1] adjoint (Fs^T / Fa^T)
+  void* h2_ana[2];
+  void* h2_syn[2];
 };
 
 namespace rpde {
