@@ -196,6 +196,10 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers); 
 /* forward scratch (optional: ws may be NULL; with it each weight is pre-split once per call for the
  * split-bf16 GEMMs -- faster, bit-identical output) */
 size_t rpde_feedforward_fwd_ws_bytes(int dim, int factor, int n_layers);
+/* 1 when rpde_feedforward_fwd (given its scratch) runs this shape as ONE fused kernel (dim 64, factor 4, three
+ * layers: hidden activations never reach HBM).  Then hs / ds may be NULL in evaluation: only `out` is written;
+ * with all of hs[0..1], ds[0..1] given the kernel also stores them and z_last for rpde_feedforward_bwd. */
+int rpde_feedforward_is_fused(int dim, int factor, int n_layers, int64_t P);
 int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual,
                          float* const* hs, float* const* ds, float* z_last, float* out, int64_t P,
                          void* ws, size_t ws_bytes, void* stream);

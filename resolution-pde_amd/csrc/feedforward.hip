@@ -10,6 +10,7 @@
 #include "rpde_internal.h"
 #include "pointwise.h"
 #include "gemm_kernel.h"
+#include "ff_fused.h"
 
 namespace rpde {
 
@@ -138,17 +139,31 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
 }
 
 size_t rpde_feedforward_fwd_ws_bytes(int dim, int factor, int n_layers) {
-  return arena_bytes(ff_wimg_floats(n_layers > 1 ? dim * factor : dim));
+  const size_t a = arena_bytes(ff_wimg_floats(n_layers > 1 ? dim * factor : dim)), b = arena_bytes(ff3_fused_ws_floats());
+  return a > b ? a : b;
+}
+
+// 1 when rpde_feedforward_fwd runs this shape as one fused kernel that needs no hidden buffers in evaluation
+int rpde_feedforward_is_fused(int dim, int factor, int n_layers, int64_t P) {
+  rpde_ff_params q;
+  memset(&q, 0, sizeof(q));
+  q.dim = dim; q.factor = factor; q.n_layers = n_layers;
+  return ff3_fused_ok(&q, (long)P) ? 1 : 0;
 }
 
 int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs,
                          float* const* ds, float* z_last, float* out, int64_t P, void* ws, size_t ws_bytes, void* stream) {
   RPDE_CHECK_ARG(p && x && z_last && out && P > 0, "feedforward_fwd: bad arguments");
   RPDE_CHECK_ARG(p->n_layers >= 1 && p->dim > 0 && p->factor > 0, "feedforward_fwd: bad shape");
-  RPDE_CHECK_ARG(p->n_layers == 1 || hs, "feedforward_fwd: hidden buffers missing");
   RPDE_CHECK_ARG(P < (1L << 31), "feedforward_fwd: too many points for one call");
   RPDE_CHECK_ARG(p->dropout_p >= 0.f && p->dropout_p < 1.f, "feedforward_fwd: dropout %f", p->dropout_p);
   hipStream_t st = as_stream(stream);
+  if (ff3_fused_ok(p, P) && ws && ws_bytes >= arena_bytes(ff3_fused_ws_floats())) {
+    RPDE_CHECK_ARG(p->weights[0] && p->weights[1] && p->weights[2], "feedforward_fwd: null weights");
+    RPDE_CHECK_ARG(!p->layer_norm || (p->ln_gamma && p->ln_beta), "feedforward_fwd: layer_norm needs gamma/beta");
+    return ff3_fused_fwd(p, x, residual, hs, ds, z_last, out, P, ws, st);
+  }
+  RPDE_CHECK_ARG(p->n_layers == 1 || hs, "feedforward_fwd: hidden buffers missing");
   const int L = p->n_layers;
   // optional scratch (rpde_feedforward_fwd_ws_bytes): weights are pre-split once per call; without it the
   // GEMMs split them per workgroup (slower, same bits)

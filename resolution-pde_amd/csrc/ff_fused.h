@@ -1,0 +1,13 @@
+// Fused three-layer FeedForward (ff_fused.hip)
+#pragma once
+#include "rpde_internal.h"
+
+namespace rpde {
+// true for the FFNO2D shape (dim 64, factor 4, three layers) and at least one tile of points
+bool ff3_fused_ok(const rpde_ff_params* p, long P);
+size_t ff3_fused_ws_floats();
+// hs / ds with all four buffers: training (h1, d1, h2, d2 and z_last are stored for rpde_feedforward_bwd);
+// otherwise evaluation: only `out` is written
+int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs, float* const* ds,
+                  float* z_last, float* out, long P, void* ws, hipStream_t st);
+}  // namespace rpde

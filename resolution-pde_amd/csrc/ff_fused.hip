@@ -1,0 +1,463 @@
+// FeedForward 64 -> 256 -> 256 -> 64 (models/custom_layer.py:49-68 with dim 64, factor 4, three layers: the FFNO2D
+// configuration) as ONE weight-stationary kernel in h2 arithmetic (h2.h).
+//
+// Everything is computed transposed (rows = features, columns = grid points), because then the accumulator of one
+// layer IS the B operand of the next: a 16x16 accumulator tile holds feature rows 4g..4g+3 of point column (l & 15)
+// in lane l, and two such tiles side by side are exactly the eight reduction entries a lane supplies to
+// v_mfma_f32_16x16x32_f16 -- with the reduction index permuted, which the pre-arranged weight fragments absorb.
+// So the hidden activations never leave the CU and never change lanes:
+//
+//   * a persistent 8-wave workgroup keeps ALL weights in registers for the whole launch: wave w owns rows
+//     32w..32w+31 of W1 and W2 (2 output tiles each) and the reduction slice 32w..32w+31 of W3 -- 48 fragments,
+//     192 VGPRs.  No weight traffic after the first microsecond.
+//   * per tile of 32 points: GEMM1 (B = the input tile, split once and shared through LDS) -> bias, dropout,
+//     GELU and GELU' in registers -> the wave's own slice of h1 goes to LDS as a ready fragment (8 KB per wave) ->
+//     GEMM2 reads all eight slices -> activation -> the wave's slice of h2 stays in registers and feeds its slice of
+//     GEMM3 -> the eight partial outputs are summed through LDS by one wave per 16 points, which also applies the
+//     last dropout, LayerNorm, post-activation and the residual.  Three workgroup barriers per tile.
+//   * training additionally stores h1, d1, h2, d2 (what rpde_feedforward_bwd consumes) and z3; evaluation stores
+//     nothing but the output: 2 x 256 B per point instead of 4.6 KB.
+//
+// Operand scaling (f16 has a 5-bit exponent): weights carry one power-of-two scale per matrix; the input tile uses
+// its own maximum; h1 and h2 use BOUNDS derived from it (|h| <= |u| <= max row L1 norm of W * max|x| + max|b|), so no
+// reduction over activations is ever needed.  A bound that is 2^k too large costs k of the ~15 spare bits of the
+// two-piece format, nothing else.
+#include "ff_fused.h"
+#include "h2.h"
+#include "pointwise.h"
+
+namespace rpde {
+
+#ifdef RPDE_STAMPS
+// debug build: lane 0 of waves 0, 3 and 6 of workgroup 100 records s_memtime around the phases of its first tiles
+__device__ unsigned long long g_ffstamps[3 * 64];
+#define FFSTAMP(i) do { if (stamp_on && stamp_t < 8) g_ffstamps[stamp_w * 64 + stamp_t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FFSTAMP(i) do { } while (0)
+#endif
+
+constexpr int FF_WAVES = 8;
+constexpr int FF_FRAGS = 24;                 // per wave: W1 4, W2 16, W3 4
+constexpr int FF_IMG_BYTES = FF_WAVES * FF_FRAGS * 2048;
+constexpr int FF_NCONST = 16;
+
+// reduction-slot -> hidden feature inside a 32-wide slice, for operands built from two accumulator tiles
+__device__ __forceinline__ int ff_perm(int g, int j) { return 16 * (j >> 2) + 4 * g + (j & 3); }
+
+// ---- weight preparation: one block; maxima first, then the fragments in per-wave register order ----
+__global__ __launch_bounds__(1024) void k_ff3_prep(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                   const float* __restrict__ w3, const float* __restrict__ b1,
+                                                   const float* __restrict__ b2, char* __restrict__ img,
+                                                   float* __restrict__ consts) {
+  __shared__ float red[6][16];
+  __shared__ float fin[6];
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  // [0..2] max |W1|, |W2|, |W3|; [3] max row L1 of W1; [4] of W2; [5] max(|b1|), [6] max(|b2|) folded into 3,4 slots below
+  float m1 = 0.f, m2 = 0.f, m3 = 0.f, r1 = 0.f, r2 = 0.f, bm = 0.f;
+  for (int i = tid; i < 256 * 64; i += 1024) { m1 = fmaxf(m1, fabsf(w1[i])); m3 = fmaxf(m3, fabsf(w3[i])); }
+  for (int i = tid; i < 256 * 256; i += 1024) m2 = fmaxf(m2, fabsf(w2[i]));
+  if (tid < 256) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < 64; ++k) a += fabsf(w1[tid * 64 + k]);
+    for (int k = 0; k < 256; ++k) b += fabsf(w2[tid * 256 + k]);
+    r1 = a; r2 = b;
+    bm = fabsf(b1 ? b1[tid] : 0.f);
+  } else if (tid < 512) {
+    bm = fabsf(b2 ? b2[tid - 256] : 0.f);          // kept apart below: threads 256..511 carry |b2|
+  }
+  float v[6] = {m1, m2, m3, r1, r2, 0.f};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { v[k] = wave_max(v[k]); if (l == 0) red[k][wv] = v[k]; }
+  const float bmw = wave_max(bm);
+  if (l == 0) red[5][wv] = bmw;
+  __syncthreads();
+  if (tid < 5) { float a = 0.f; for (int i = 0; i < 16; ++i) a = fmaxf(a, red[tid][i]); fin[tid] = a; }
+  if (tid == 5) { float a = 0.f; for (int i = 0; i < 4; ++i) a = fmaxf(a, red[5][i]); fin[5] = a; }       // |b1|: waves 0..3
+  __shared__ float fin_b2;
+  if (tid == 6) { float a = 0.f; for (int i = 4; i < 8; ++i) a = fmaxf(a, red[5][i]); fin_b2 = a; }       // |b2|: waves 4..7
+  __syncthreads();
+  float sc[3], iv[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h2_scale(fin[k], 0, sc[k], iv[k]);
+  if (tid == 0) {
+    consts[0] = iv[0]; consts[1] = iv[1]; consts[2] = iv[2];
+    consts[3] = fin[3]; consts[4] = fin[4]; consts[5] = fin[5]; consts[6] = fin_b2;
+  }
+  // fragments: (wave, frag, lane) -> eight entries, scaled and split
+  for (int it = tid; it < FF_WAVES * FF_FRAGS * 64; it += 1024) {
+    const int ln = it & 63, f = (it >> 6) % FF_FRAGS, w = it / (64 * FF_FRAGS);
+    const int g = ln >> 4, li = ln & 15;
+    float x[8];
+    if (f < 4) {                 // W1, natural reduction order: tile 2w + (f>>1), k-step f&1
+      const int row = 16 * (2 * w + (f >> 1)) + li, k0 = 32 * (f & 1) + 8 * g;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = w1[row * 64 + k0 + j] * sc[0];
+    } else if (f < 20) {         // W2, permuted: tile 2w + ((f-4)>>3), slice kappa = (f-4)&7
+      const int row = 16 * (2 * w + ((f - 4) >> 3)) + li, kap = (f - 4) & 7;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = w2[row * 256 + 32 * kap + ff_perm(g, j)] * sc[1];
+    } else {                     // W3, permuted: output tile f-20, slice kappa = w
+      const int row = 16 * (f - 20) + li;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = w3[row * 256 + 32 * w + ff_perm(g, j)] * sc[2];
+    }
+    uint2 h0, l0, h1, l1;
+    h2_split4(x[0], x[1], x[2], x[3], h0, l0);
+    h2_split4(x[4], x[5], x[6], x[7], h1, l1);
+    char* p = img + ((long)(w * FF_FRAGS + f)) * 2048 + ln * 16;
+    *reinterpret_cast<uint4*>(p) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4*>(p + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  }
+}
+
+struct FF3P {
+  const float* x; const float* res; float* out; float* z3;
+  float* h1; float* d1; float* h2; float* d2;          // null in evaluation
+  const char* wimg; const float* consts;
+  const float* b1; const float* b2; const float* b3; const float* gamma; const float* beta;
+  long P; int layer_norm; float eps; int post_act;
+  DropCfg drop[3];
+  int ntiles;
+};
+
+// LDS map (bytes)
+constexpr int FF_SBUF = 0;                        // [2 blk][2 ks][hi|lo][1 KB]: input tile as B fragments       =  8 KB
+constexpr int FF_RAW = FF_SBUF + 8192;            // [2 blk][4 pieces][1 KB]: fp32 of the NEXT input tile (LDS-DMA) =  8 KB
+constexpr int FF_HBUF = FF_RAW + 8192;            // [2 blk][8 kappa][hi|lo][1 KB]: h1 slices                     = 32 KB
+constexpr int FF_H2BUF = FF_HBUF + 32768;         // the same for h2                                              = 32 KB
+constexpr int FF_W3 = FF_H2BUF + 32768;           // [4 tile][8 kappa][hi|lo][1 KB]: all of W3                    = 64 KB
+constexpr int FF_VEC = FF_W3 + 65536;             // b1[256] b2[256] b3[64] gamma[64] beta[64] floats             = 2816 B
+constexpr int FF_STAT = FF_VEC + 2816;            // [2 blk][4 tile][16 points][mean, M2] floats                  =  1 KB
+constexpr int FF_INFO = FF_STAT + 1024;           // [2 blk] floats: maximum of the input block
+constexpr int FF_LDS = FF_INFO + 64;
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for every outstanding global
+// store (the h / d tensors a training forward writes) several times per tile
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// bias, dropout, GELU on four consecutive features of one point; h and d = gelu'(u) * dropscale out
+__device__ __forceinline__ void ff_act4(const f32x4v acc, float inv, const float4 b, const DropCfg& drop, uint64_t id,
+                                        float (&h)[4], float (&d)[4]) {
+  float s[4] = {1.f, 1.f, 1.f, 1.f};
+  if (drop.on()) drop_scale4(drop, id, s);
+  const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float u = fmaf(acc[r], inv, bb[r]) * s[r];
+    act_both(RPDE_ACT_GELU, u, h[r], d[r]);
+    d[r] *= s[r];
+  }
+}
+
+// eight scaled activations of a lane (two accumulator tiles) -> one B fragment (hi, lo) at dst / dst + 1 KB
+__device__ __forceinline__ void ff_put_frag(char* dst, const float (&v)[8]) {
+  uint2 h0, l0, h1, l1;
+  h2_split4(v[0], v[1], v[2], v[3], h0, l0);
+  h2_split4(v[4], v[5], v[6], v[7], h1, l1);
+  *reinterpret_cast<uint4*>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
+  __shared__ __attribute__((aligned(16))) char smem[FF_LDS];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, li = l & 15;
+  // ---- W1, W2 slices -> registers; W3, biases, LayerNorm vectors -> LDS; once ----
+  f16x8 w1h[2][2], w1l[2][2], w2h[2][8], w2l[2][8];
+  {
+    const char* base = A.wimg + (long)w * FF_FRAGS * 2048 + l * 16;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      w1h[f >> 1][f & 1] = *reinterpret_cast<const f16x8*>(base + f * 2048);
+      w1l[f >> 1][f & 1] = *reinterpret_cast<const f16x8*>(base + f * 2048 + 1024);
+    }
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      w2h[f >> 3][f & 7] = *reinterpret_cast<const f16x8*>(base + (4 + f) * 2048);
+      w2l[f >> 3][f & 7] = *reinterpret_cast<const f16x8*>(base + (4 + f) * 2048 + 1024);
+    }
+    // the image holds W3 as [wave = kappa][tile]; LDS wants [tile][kappa]
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint4 hi = *reinterpret_cast<const uint4*>(base + (20 + f) * 2048);
+      const uint4 lo = *reinterpret_cast<const uint4*>(base + (20 + f) * 2048 + 1024);
+      *reinterpret_cast<uint4*>(smem + FF_W3 + (f * 8 + w) * 2048 + l * 16) = hi;
+      *reinterpret_cast<uint4*>(smem + FF_W3 + (f * 8 + w) * 2048 + 1024 + l * 16) = lo;
+    }
+    float* vec = reinterpret_cast<float*>(smem + FF_VEC);
+    for (int i = tid; i < 704; i += 64 * FF_WAVES) {
+      float v;
+      if (i < 256) v = A.b1 ? A.b1[i] : 0.f;
+      else if (i < 512) v = A.b2 ? A.b2[i - 256] : 0.f;
+      else if (i < 576) v = A.b3 ? A.b3[i - 512] : 0.f;
+      else if (i < 640) v = A.gamma ? A.gamma[i - 576] : 1.f;
+      else v = A.beta ? A.beta[i - 640] : 0.f;
+      vec[i] = v;
+    }
+  }
+  const float* const vec = reinterpret_cast<const float*>(smem + FF_VEC);
+  const float winv1 = A.consts[0], winv2 = A.consts[1], winv3 = A.consts[2];
+  const float c1 = A.consts[3], c2 = A.consts[4], b1max = A.consts[5], b2max = A.consts[6];
+  float* const info = reinterpret_cast<float*>(smem + FF_INFO);
+  float* const stat = reinterpret_cast<float*>(smem + FF_STAT);
+
+  // input tile: wave `blk` (0, 1) owns 16 points.  Their 4 KB are fetched by LDS-DMA one tile ahead (each lane's four
+  // 16-byte pieces land at [piece][lane], no registers held meanwhile) and turned into scaled f16 pieces afterwards.
+  auto s_issue = [&](int tile) {
+    const long p = min((long)tile * 32 + 16 * w + li, A.P - 1);
+    const float* q = A.x + p * 64 + 8 * g;
+    char* dst = smem + FF_RAW + w * 4096;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(q), (lds_ptr)(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(q + 4), (lds_ptr)(dst + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(q + 32), (lds_ptr)(dst + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr)(q + 36), (lds_ptr)(dst + 3072), 16, 0, 0);
+  };
+  auto s_convert = [&]() {
+    float4 sn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sn[i] = *reinterpret_cast<const float4*>(smem + FF_RAW + w * 4096 + i * 1024 + l * 16);
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(sn[i].x), "v"(sn[i].y));
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(sn[i].z), "v"(sn[i].w));
+    }
+    m = wave_max(m);
+    float sc, iv;
+    h2_scale(m, 0, sc, iv);
+    char* dst = smem + FF_SBUF + (w * 2) * 2048 + l * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float v[8] = {sn[2 * ks].x * sc, sn[2 * ks].y * sc, sn[2 * ks].z * sc, sn[2 * ks].w * sc,
+                          sn[2 * ks + 1].x * sc, sn[2 * ks + 1].y * sc, sn[2 * ks + 1].z * sc, sn[2 * ks + 1].w * sc};
+      ff_put_frag(dst + ks * 2048, v);
+    }
+    if (l == 0) info[w] = m;
+  };
+  if (w < 2 && (int)blockIdx.x < A.ntiles) {
+    s_issue(blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_convert();
+  }
+  // role in the last layer: output tile t3 (16 features) of point block b3
+  const int t3 = w & 3, b3 = w >> 2;
+
+#ifdef RPDE_STAMPS
+  const bool stamp_on = blockIdx.x == 100 && l == 0 && (w == 0 || w == 3 || w == 6);
+  const int stamp_w = w == 0 ? 0 : (w == 3 ? 1 : 2);
+  int stamp_t = -4;                      // skip the first four tiles (cold caches)
+#endif
+  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    FFSTAMP(0);
+    lds_barrier();                         // B0: input fragments of this tile (and, first time, W3 / vectors) are in LDS
+    FFSTAMP(1);
+    const int next_tile = tile + gridDim.x;
+    if (w < 2 && next_tile < A.ntiles) s_issue(next_tile);
+    const long p0 = (long)tile * 32;
+
+    // per 16-point block: scales of x (exact maximum), h1 and h2 (bounds); wave-uniform
+    float inv1[2], sh1[2], inv2[2], sh2[2], inv3[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const float smax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(info[blk])));
+      float sx, sxi, a, ai;
+      h2_scale(smax, 0, sx, sxi);
+      inv1[blk] = sxi * winv1;
+      const float bound1 = fmaf(c1, smax, b1max) * A.drop[0].scale;
+      h2_scale(bound1, 0, a, ai);
+      sh1[blk] = a; inv2[blk] = ai * winv2;
+      const float bound2 = fmaf(c2, bound1, b2max) * A.drop[1].scale;
+      h2_scale(bound2, 0, a, ai);
+      sh2[blk] = a; inv3[blk] = ai * winv3;
+    }
+
+    // ---- layer 1: this wave's 32 hidden features of both point blocks -> h1 slice w ----
+    // (issuing the four accumulator chains interleaved was tried: no faster -- the phase is bound by the vector work
+    //  of the activation -- and its extra live fragments spilled)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const char* sb = smem + FF_SBUF + (blk * 2) * 2048 + l * 16;
+      const f16x8 xh0 = *reinterpret_cast<const f16x8*>(sb), xl0 = *reinterpret_cast<const f16x8*>(sb + 1024);
+      const f16x8 xh1 = *reinterpret_cast<const f16x8*>(sb + 2048), xl1 = *reinterpret_cast<const f16x8*>(sb + 3072);
+      const long pt = p0 + 16 * blk + li;
+      float hv[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        acc = h2_mfma32(w1h[t][0], w1l[t][0], xh0, xl0, acc);
+        acc = h2_mfma32(w1h[t][1], w1l[t][1], xh1, xl1, acc);
+        float h[4], d[4];
+        const int hid = 16 * (2 * w + t) + 4 * g;
+        ff_act4(acc, inv1[blk], *reinterpret_cast<const float4*>(vec + hid), A.drop[0], (uint64_t)(pt * 256 + hid), h, d);
+        if (TRAIN && pt < A.P) {
+          *reinterpret_cast<float4*>(A.h1 + pt * 256 + hid) = make_float4(h[0], h[1], h[2], h[3]);
+          *reinterpret_cast<float4*>(A.d1 + pt * 256 + hid) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[4 * t + r] = h[r] * sh1[blk];
+      }
+      ff_put_frag(smem + FF_HBUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
+    }
+    FFSTAMP(2);
+    lds_barrier();                         // B1: all eight slices of h1 are in LDS
+    FFSTAMP(3);
+
+    // residual of this wave's output tile: needed after the last layer, fetched now
+    const long pt3 = p0 + 16 * b3 + li;
+    const long off3 = min(pt3, A.P - 1) * 64 + 16 * t3 + 4 * g;
+    float4 resv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (A.res) resv = *reinterpret_cast<const float4*>(A.res + off3);
+
+    // ---- layer 2 (reads every slice of h1) -> h2 slice w ----
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kap = 0; kap < 8; ++kap) {
+        const char* hb = smem + FF_HBUF + ((blk * 8 + kap) * 2) * 1024 + l * 16;
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(hb), bl = *reinterpret_cast<const f16x8*>(hb + 1024);
+        acc[0] = h2_mfma32(w2h[0][kap], w2l[0][kap], bh, bl, acc[0]);
+        acc[1] = h2_mfma32(w2h[1][kap], w2l[1][kap], bh, bl, acc[1]);
+      }
+      const long pt = p0 + 16 * blk + li;
+      float hv[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float h[4], d[4];
+        const int hid = 16 * (2 * w + t) + 4 * g;
+        ff_act4(acc[t], inv2[blk], *reinterpret_cast<const float4*>(vec + 256 + hid), A.drop[1], (uint64_t)(pt * 256 + hid), h, d);
+        if (TRAIN && pt < A.P) {
+          *reinterpret_cast<float4*>(A.h2 + pt * 256 + hid) = make_float4(h[0], h[1], h[2], h[3]);
+          *reinterpret_cast<float4*>(A.d2 + pt * 256 + hid) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[4 * t + r] = h[r] * sh2[blk];
+      }
+      ff_put_frag(smem + FF_H2BUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
+    }
+    FFSTAMP(4);
+    lds_barrier();                         // B2: all eight slices of h2 are in LDS
+    FFSTAMP(5);
+
+    // ---- layer 3: output tile t3 of point block b3, both operands from LDS ----
+    f32x4v acc3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kap = 0; kap < 8; ++kap) {
+      const char* wb = smem + FF_W3 + (t3 * 8 + kap) * 2048 + l * 16;
+      const char* hb = smem + FF_H2BUF + ((b3 * 8 + kap) * 2) * 1024 + l * 16;
+      acc3 = h2_mfma32(*reinterpret_cast<const f16x8*>(wb), *reinterpret_cast<const f16x8*>(wb + 1024),
+                       *reinterpret_cast<const f16x8*>(hb), *reinterpret_cast<const f16x8*>(hb + 1024), acc3);
+    }
+    if (w < 2 && next_tile < A.ntiles) {
+      // the DMA of the next input tile was issued before this tile's stores (16 when training): it is older than the
+      // eight youngest of them, so vmcnt(8) covers it without waiting for all stores to be acknowledged
+      if (TRAIN) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_convert();
+    }
+    float v[4];
+    {
+      const float4 bb = *reinterpret_cast<const float4*>(vec + 512 + 16 * t3 + 4 * g);
+      v[0] = fmaf(acc3[0], inv3[b3], bb.x); v[1] = fmaf(acc3[1], inv3[b3], bb.y);
+      v[2] = fmaf(acc3[2], inv3[b3], bb.z); v[3] = fmaf(acc3[3], inv3[b3], bb.w);
+      if (TRAIN && pt3 < A.P) *reinterpret_cast<float4*>(A.z3 + off3) = make_float4(v[0], v[1], v[2], v[3]);
+      if (A.drop[2].on()) {
+        float s4[4];
+        drop_scale4(A.drop[2], (uint64_t)(pt3 * 64 + 16 * t3 + 4 * g), s4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= s4[r];
+      }
+    }
+    if (A.layer_norm) {
+      // LayerNorm over 64 features = 4 waves x 4 lane groups x 4 registers: each wave reduces its 16 features of a
+      // point to (mean, M2), the four are combined exactly (pairwise update of Chan et al.): as accurate as the
+      // reference's two-pass variance, with one exchange through LDS
+      float sum = (v[0] + v[1]) + (v[2] + v[3]);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mw = sum * (1.f / 16.f);
+      float m2 = (v[0] - mw) * (v[0] - mw) + (v[1] - mw) * (v[1] - mw) + (v[2] - mw) * (v[2] - mw) + (v[3] - mw) * (v[3] - mw);
+      m2 += __shfl_xor(m2, 16, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      if (g == 0) *reinterpret_cast<float2*>(stat + ((b3 * 4 + t3) * 16 + li) * 2) = make_float2(mw, m2);
+    }
+    lds_barrier();                         // B3: per-wave statistics are in LDS (also: everyone is done with h2 / stats of the previous tile)
+    if (A.layer_norm) {
+      float mws[4], m2s = 0.f, mean = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float2 s2 = *reinterpret_cast<const float2*>(stat + ((b3 * 4 + t) * 16 + li) * 2);
+        mws[t] = s2.x; m2s += s2.y; mean += s2.x;
+      }
+      mean *= 0.25f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) m2s += 16.f * (mws[t] - mean) * (mws[t] - mean);
+      const float rstd = rsqrtf(m2s * (1.f / 64.f) + A.eps);
+      const float4 gm = *reinterpret_cast<const float4*>(vec + 576 + 16 * t3 + 4 * g);
+      const float4 bt = *reinterpret_cast<const float4*>(vec + 640 + 16 * t3 + 4 * g);
+      v[0] = (v[0] - mean) * rstd * gm.x + bt.x; v[1] = (v[1] - mean) * rstd * gm.y + bt.y;
+      v[2] = (v[2] - mean) * rstd * gm.z + bt.z; v[3] = (v[3] - mean) * rstd * gm.w + bt.w;
+    }
+    if (A.post_act) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = act_f(A.post_act, v[r]);
+    }
+    if (pt3 < A.P) *reinterpret_cast<float4*>(A.out + off3) = make_float4(v[0] + resv.x, v[1] + resv.y, v[2] + resv.z, v[3] + resv.w);
+    FFSTAMP(6);
+#ifdef RPDE_STAMPS
+    ++stamp_t;
+#endif
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+bool ff3_fused_ok(const rpde_ff_params* p, long P) {
+  if (const char* e = getenv("RPDE_FUSED_FF")) if (e[0] == '0') return false;
+  return p->n_layers == 3 && p->dim == 64 && p->factor == 4 && P >= 32;
+}
+size_t ff3_fused_ws_floats() { return (FF_IMG_BYTES + FF_NCONST * 4 + 3) / 4; }
+
+int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs, float* const* ds,
+                  float* z_last, float* out, long P, void* ws, hipStream_t st) {
+  char* img = static_cast<char*>(ws);
+  float* consts = reinterpret_cast<float*>(img + FF_IMG_BYTES);
+  const float* b1 = p->biases ? p->biases[0] : nullptr;
+  const float* b2 = p->biases ? p->biases[1] : nullptr;
+  const float* b3 = p->biases ? p->biases[2] : nullptr;
+  hipLaunchKernelGGL(k_ff3_prep, dim3(1), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], b1, b2, img, consts);
+  RPDE_LAUNCH_CHECK();
+  FF3P A;
+  memset(&A, 0, sizeof(A));
+  const bool train = hs && ds && hs[0] && hs[1] && ds[0] && ds[1];
+  A.x = x; A.res = residual; A.out = out; A.z3 = z_last;
+  if (train) { A.h1 = hs[0]; A.d1 = ds[0]; A.h2 = hs[1]; A.d2 = ds[1]; }
+  A.wimg = img; A.consts = consts; A.b1 = b1; A.b2 = b2; A.b3 = b3; A.gamma = p->ln_gamma; A.beta = p->ln_beta;
+  A.P = P; A.layer_norm = p->layer_norm; A.eps = p->ln_eps; A.post_act = p->post_act;
+  for (int l = 0; l < 3; ++l) {
+    // same (seed, layer) -> mask mapping as the per-GEMM path, so that rpde_feedforward_bwd regenerates the same masks
+    uint64_t z = p->seed + 0x9E3779B97F4A7C15ull * (uint64_t)(l + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    A.drop[l] = make_drop(p->dropout_p, z ^ (z >> 31));
+  }
+  A.ntiles = (int)((P + 31) / 32);
+  int dev = 0, cus = 256;
+  RPDE_HIP(hipGetDevice(&dev));
+  RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grid = A.ntiles < cus ? A.ntiles : cus;
+  if (train) hipLaunchKernelGGL(k_ff3_fwd_h2<true>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
+  else hipLaunchKernelGGL(k_ff3_fwd_h2<false>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+}  // namespace rpde
+
+#ifdef RPDE_STAMPS
+extern "C" int rpde_debug_ff_stamps(unsigned long long* host_out) {
+  RPDE_HIP(hipDeviceSynchronize());
+  RPDE_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rpde::g_ffstamps), sizeof(unsigned long long) * 3 * 64));
+  return RPDE_OK;
+}
+#endif

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "rpde_spectral2d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_feedforward_ws_bytes": (_Z, [_L, _I, _I, _I]),
     "rpde_feedforward_fwd_ws_bytes": (_Z, [_I, _I, _I]),
+    "rpde_feedforward_is_fused": (_I, [_I, _I, _I, _L]),
     "rpde_feedforward_fwd": (_I, [C.POINTER(FFParams), _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
     "rpde_feedforward_bwd": (_I, [C.POINTER(FFParams), _P, _PP, _PP, _P, _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
     "rpde_linear_ws_bytes": (_Z, [_L, _I, _I]),

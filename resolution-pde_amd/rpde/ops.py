@@ -145,7 +145,7 @@ class _FeedForward(torch.autograd.Function):
         """cfg = (n_layers, dim, factor, layer_norm, eps, dropout_p, seed, post_act)
         params = W0, b0, ..., W_{L-1}, b_{L-1} [, gamma, beta]"""
         lib = load()
-        L, dim, factor, layer_norm, eps, p_drop, seed, post_act = cfg
+        L, dim, factor, layer_norm, eps, p_drop, seed, post_act, grad_on = cfg
         shape = x.shape
         x2 = _f32c(x).reshape(-1, dim)
         P = x2.shape[0]
@@ -154,9 +154,11 @@ class _FeedForward(torch.autograd.Function):
         bs_ = [_f32c(params[2 * l + 1]) for l in range(L)]
         gamma = _f32c(params[2 * L]) if layer_norm else None
         beta = _f32c(params[2 * L + 1]) if layer_norm else None
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = grad_on and any(ctx.needs_input_grad)     # (grad mode is always off inside forward itself)
         hid = dim * factor
-        hs = [torch.empty(P, hid, dtype=torch.float32, device=x.device) for _ in range(L - 1)]
+        # the fused kernel keeps the hidden activations on chip: in evaluation nothing but `out` is allocated
+        lean = (not need_grad) and bool(lib.rpde_feedforward_is_fused(dim, factor, L, P))
+        hs = [None if lean else torch.empty(P, hid, dtype=torch.float32, device=x.device) for _ in range(L - 1)]
         ds = [torch.empty(P, hid, dtype=torch.float32, device=x.device) if need_grad else None for _ in range(L - 1)]
         z_last = torch.empty(P, dim, dtype=torch.float32, device=x.device)
         out = torch.empty(P, dim, dtype=torch.float32, device=x.device)
@@ -177,7 +179,7 @@ class _FeedForward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         lib = load()
-        L, dim, factor, layer_norm, eps, p_drop, seed, post_act = ctx.cfg
+        L, dim, factor, layer_norm, eps, p_drop, seed, post_act, _ = ctx.cfg
         saved = ctx.saved_tensors
         x2, z_last = saved[0], saved[1]
         o = 2
@@ -219,7 +221,8 @@ def feedforward(x, residual, weights: Sequence[torch.Tensor], biases: Sequence[t
         params += [w, b]
     if ln is not None:
         params += [ln[0], ln[1]]
-    cfg = (L, int(dim), int(factor), ln is not None, float(eps), float(dropout_p), int(seed) & (2 ** 64 - 1), ACT[post_act])
+    cfg = (L, int(dim), int(factor), ln is not None, float(eps), float(dropout_p), int(seed) & (2 ** 64 - 1), ACT[post_act],
+           torch.is_grad_enabled())
     return _FeedForward.apply(x, residual, cfg, *params)
 
 
