@@ -135,7 +135,13 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
   if (t > small) small = t;
   const size_t c = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
   if (c > small) small = c;
-  return 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small) + arena_bytes(ff_wimg_floats(hid));
+  size_t n = 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small) + arena_bytes(ff_wimg_floats(hid));
+  rpde_ff_params q;
+  memset(&q, 0, sizeof(q));
+  q.dim = dim; q.factor = factor; q.n_layers = n_layers;
+  if (ff3_fused_ok(&q, (long)P))           // + dz3, the per-workgroup sums, the weight fragments of the fused kernel
+    n += arena_bytes((size_t)P * dim) + arena_bytes(ff3_fused_bwd_part_floats()) + arena_bytes(ff3_fused_ws_floats());
+  return n;
 }
 
 size_t rpde_feedforward_fwd_ws_bytes(int dim, int factor, int n_layers) {
@@ -204,6 +210,32 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   float* small = ar.take(small_n);
   void* wt = ar.take(ff_wimg_floats(hid));
   if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
+
+  if (ff3_fused_ok(p, P) && hs && ds && hs[0] && hs[1] && ds[0] && ds[1]) {
+    // one fused kernel for the LayerNorm / dropout adjoint and the whole data-gradient chain; then the three
+    // weight-gradient GEMMs on what it stored
+    float* dz3 = ar.take((size_t)P * p->dim);
+    float* part = ar.take(ff3_fused_bwd_part_floats());
+    void* fimg = ar.take(ff3_fused_ws_floats());
+    if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
+    int grid = 0;
+    RPDE_TRY(ff3_fused_bwd_launch(p, ds, z_last, grad_out, dz3, buf0, buf1, grad_x, part, &grid, P, fimg, st));
+    if (grad_weights) {
+      RPDE_TRY(linear_wgrad_impl(hs[1], dz3, grad_weights[2], nullptr, P, hid, p->dim, slabs, small, st));
+      RPDE_TRY(linear_wgrad_impl(hs[0], buf0, grad_weights[1], nullptr, P, hid, hid, slabs, small, st));
+      RPDE_TRY(linear_wgrad_impl(x, buf1, grad_weights[0], nullptr, P, p->dim, hid, slabs, small, st));
+    }
+    if (grad_biases) {
+      RPDE_TRY(reduce_slabs(part, grad_biases[0], hid, grid, FF3_PART, 1.f, 0, st));
+      RPDE_TRY(reduce_slabs(part + 256, grad_biases[1], hid, grid, FF3_PART, 1.f, 0, st));
+      RPDE_TRY(reduce_slabs(part + 512, grad_biases[2], p->dim, grid, FF3_PART, 1.f, 0, st));
+    }
+    if (p->layer_norm) {
+      if (grad_gamma) RPDE_TRY(reduce_slabs(part + 576, grad_gamma, p->dim, grid, FF3_PART, 1.f, 0, st));
+      if (grad_beta) RPDE_TRY(reduce_slabs(part + 640, grad_beta, p->dim, grid, FF3_PART, 1.f, 0, st));
+    }
+    return RPDE_OK;
+  }
 
   // tail: d(out) -> dz_{L-1}, d(gamma), d(beta) and, fused, the last layer's bias gradient
   float* dz = buf0;

@@ -10,4 +10,10 @@ size_t ff3_fused_ws_floats();
 // otherwise evaluation: only `out` is written
 int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs, float* const* ds,
                   float* z_last, float* out, long P, void* ws, hipStream_t st);
+// backward: everything except the three weight-gradient GEMMs (feedforward.hip runs those on dz3 / du2 / du1)
+constexpr int FF3_PART = 704;            // per workgroup: db1[256] db2[256] db3[64] dgamma[64] dbeta[64]
+size_t ff3_fused_bwd_part_floats();
+int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, const float* z_last, const float* grad_out,
+                         float* dz3, float* du2, float* du1, float* dx, float* part, int* grid_out, long P, void* ws,
+                         hipStream_t st);
 }  // namespace rpde

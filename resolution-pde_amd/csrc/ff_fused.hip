@@ -273,6 +273,10 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
       sh2[blk] = a; inv3[blk] = ai * winv3;
     }
 
+    // (tried and dropped, same-box A/B: issuing the accumulator chains of a layer interleaved (no faster: the phases
+    //  are bound by the vector work of the activation; the extra live fragments spilled), and a two-barrier software
+    //  pipeline across tiles -- layer 3 of tile i beside layer 1 of tile i+1 -- (1.75 vs 1.76 ms in evaluation: the two
+    //  waves of a SIMD still run the same instruction mix at the same time, so matrix and vector work do not overlap))
     // ---- layer 1: this wave's 32 hidden features of both point blocks -> h1 slice w ----
     // (issuing the four accumulator chains interleaved was tried: no faster -- the phase is bound by the vector work
     //  of the activation -- and its extra live fragments spilled)
@@ -411,6 +415,402 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
   }
 }
 
+// ============================================================================================================
+// backward: LayerNorm / dropout / post-activation adjoint -> dz3, then the data-gradient chain
+//   du2 = (W3^T dz3) * d2,  du1 = (W2^T du2) * d1,  dx = W1^T du1
+// in the same weight-stationary, transposed form (wave w owns hidden rows 32w..32w+31 of W3^T and W2^T; W1^T lives in
+// LDS).  The kernel reads g, z3, d2, d1 and writes dz3, du2, du1 (the operands of the three weight-gradient GEMMs
+// that follow) and dx; bias, gamma and beta gradients are summed per workgroup in LDS by single-writer updates (bitwise
+// reproducible) and reduced over workgroups afterwards.
+// ============================================================================================================
+__global__ __launch_bounds__(1024) void k_ff3_prep_bwd(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                       const float* __restrict__ w3, char* __restrict__ img,
+                                                       float* __restrict__ consts) {
+  __shared__ float red[5][16];
+  __shared__ float fin[5];
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  float m1 = 0.f, m2 = 0.f, m3 = 0.f, r3 = 0.f, r2 = 0.f;
+  for (int i = tid; i < 256 * 64; i += 1024) { m1 = fmaxf(m1, fabsf(w1[i])); m3 = fmaxf(m3, fabsf(w3[i])); }
+  for (int i = tid; i < 256 * 256; i += 1024) m2 = fmaxf(m2, fabsf(w2[i]));
+  if (tid < 256) {               // column L1 norms: what bounds a row of the transposed products
+    float a = 0.f, b = 0.f;
+    for (int f = 0; f < 64; ++f) a += fabsf(w3[f * 256 + tid]);
+    for (int k = 0; k < 256; ++k) b += fabsf(w2[k * 256 + tid]);
+    r3 = a; r2 = b;
+  }
+  float v[5] = {m1, m2, m3, r3, r2};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { v[k] = wave_max(v[k]); if (l == 0) red[k][wv] = v[k]; }
+  __syncthreads();
+  if (tid < 5) { float a = 0.f; for (int i = 0; i < 16; ++i) a = fmaxf(a, red[tid][i]); fin[tid] = a; }
+  __syncthreads();
+  float sc[3], iv[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h2_scale(fin[k], 0, sc[k], iv[k]);
+  if (tid == 0) { consts[0] = iv[0]; consts[1] = iv[1]; consts[2] = iv[2]; consts[3] = fin[3]; consts[4] = fin[4]; }
+  for (int it = tid; it < FF_WAVES * FF_FRAGS * 64; it += 1024) {
+    const int ln = it & 63, f = (it >> 6) % FF_FRAGS, w = it / (64 * FF_FRAGS);
+    const int g = ln >> 4, li = ln & 15;
+    float x[8];
+    if (f < 4) {                 // W3^T: hidden tile 2w + (f>>1), reduction over the 64 output features, half f&1
+      const int hid = 16 * (2 * w + (f >> 1)) + li;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = w3[(32 * (f & 1) + ff_perm(g, j)) * 256 + hid] * sc[2];
+    } else if (f < 20) {         // W2^T: hidden-1 tile 2w + ((f-4)>>3), reduction slice kappa of hidden-2
+      const int hid1 = 16 * (2 * w + ((f - 4) >> 3)) + li, kap = (f - 4) & 7;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = w2[(32 * kap + ff_perm(g, j)) * 256 + hid1] * sc[1];
+    } else {                     // W1^T: input-feature tile f-20, reduction slice kappa = w of hidden-1
+      const int feat = 16 * (f - 20) + li;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = w1[(32 * w + ff_perm(g, j)) * 64 + feat] * sc[0];
+    }
+    uint2 h0, l0, h1, l1;
+    h2_split4(x[0], x[1], x[2], x[3], h0, l0);
+    h2_split4(x[4], x[5], x[6], x[7], h1, l1);
+    char* p = img + ((long)(w * FF_FRAGS + f)) * 2048 + ln * 16;
+    *reinterpret_cast<uint4*>(p) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4*>(p + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  }
+}
+
+constexpr int FFB_PART = 704;          // per workgroup: db1[256] db2[256] db3[64] dgamma[64] dbeta[64]
+struct FF3B {
+  const float* g; const float* z3; const float* d1; const float* d2;
+  float* dz3; float* du2; float* du1; float* dx;
+  const char* wimg; const float* consts;
+  const float* gamma; const float* beta;
+  float* part;
+  long P; int layer_norm; float eps; int post_act;
+  DropCfg drop2;
+  float dmax;            // bound of |gelu'| * dropout scale
+  int ntiles;
+};
+
+constexpr int FB_DZBUF = 0;                        // [2 blk][2 ks][hi|lo][1 KB]                              =  8 KB
+constexpr int FB_DUBUF = FB_DZBUF + 8192;          // [2 blk][8 kappa][hi|lo][1 KB]: du2 slices               = 32 KB
+constexpr int FB_DU1BUF = FB_DUBUF;                // du1 slices reuse the area (one extra barrier between reading du2 and writing du1)
+constexpr int FB_W3L = FB_DUBUF + 32768;           // [8 wave][4 frag][1 KB]: low pieces of the W3^T fragments  = 32 KB
+constexpr int FB_W1T = FB_W3L + 32768;             // [4 tile][8 kappa][hi|lo][1 KB]                          = 64 KB
+constexpr int FB_VEC = FB_W1T + 65536;             // gamma[64] beta[64]
+constexpr int FB_ACC = FB_VEC + 512;               // db1[256] db2[256] db3[2][64] dgamma[2][64] dbeta[2][64] = 3584 B
+constexpr int FB_STAT1 = FB_ACC + 3584;            // [2 blk][4 tile][16 points][mean, M2]                    = 1 KB
+constexpr int FB_STAT2 = FB_STAT1 + 1024;          // [2 blk][4 tile][16 points][s1, s2, amax, -]             = 2 KB
+constexpr int FB_INFO = FB_STAT2 + 2048;           // [2 blk] bound of |dz3|
+constexpr int FB_LDS = FB_INFO + 64;
+
+// sum over the 16 lanes of a row (one point block), valid in lane 15 of the row
+__device__ __forceinline__ float row_sum15(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));
+  return v;
+}
+
+__global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
+  __shared__ __attribute__((aligned(16))) char smem[FB_LDS];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, li = l & 15;
+  f16x8 w3h[2][2], w2h[2][8], w2l[2][8];
+  {
+    const char* base = A.wimg + (long)w * FF_FRAGS * 2048 + l * 16;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      w3h[f >> 1][f & 1] = *reinterpret_cast<const f16x8*>(base + f * 2048);
+      *reinterpret_cast<uint4*>(smem + FB_W3L + (w * 4 + f) * 1024 + l * 16) = *reinterpret_cast<const uint4*>(base + f * 2048 + 1024);
+    }
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      w2h[f >> 3][f & 7] = *reinterpret_cast<const f16x8*>(base + (4 + f) * 2048);
+      w2l[f >> 3][f & 7] = *reinterpret_cast<const f16x8*>(base + (4 + f) * 2048 + 1024);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint4 hi = *reinterpret_cast<const uint4*>(base + (20 + f) * 2048);
+      const uint4 lo = *reinterpret_cast<const uint4*>(base + (20 + f) * 2048 + 1024);
+      *reinterpret_cast<uint4*>(smem + FB_W1T + (f * 8 + w) * 2048 + l * 16) = hi;
+      *reinterpret_cast<uint4*>(smem + FB_W1T + (f * 8 + w) * 2048 + 1024 + l * 16) = lo;
+    }
+    float* vecw = reinterpret_cast<float*>(smem + FB_VEC);
+    float* accw = reinterpret_cast<float*>(smem + FB_ACC);
+    for (int i = tid; i < 128; i += 64 * FF_WAVES) vecw[i] = i < 64 ? (A.gamma ? A.gamma[i] : 1.f) : (A.beta ? A.beta[i - 64] : 0.f);
+    for (int i = tid; i < 896; i += 64 * FF_WAVES) accw[i] = 0.f;
+  }
+  const float* const vec = reinterpret_cast<const float*>(smem + FB_VEC);
+  float* const acc_db1 = reinterpret_cast<float*>(smem + FB_ACC);
+  float* const acc_db2 = acc_db1 + 256;
+  float* const acc_db3 = acc_db1 + 512;        // [2][64]
+  float* const acc_dg = acc_db1 + 640;         // [2][64]
+  float* const acc_dbt = acc_db1 + 768;        // [2][64]
+  float* const stat1 = reinterpret_cast<float*>(smem + FB_STAT1);
+  float* const stat2 = reinterpret_cast<float*>(smem + FB_STAT2);
+  float* const info = reinterpret_cast<float*>(smem + FB_INFO);
+  const float winv1 = A.consts[0], winv2 = A.consts[1], winv3 = A.consts[2], c3t = A.consts[3], c2t = A.consts[4];
+  const int t3 = w & 3, b3 = w >> 2;           // role in the pointwise phases: 16 features x 16 points
+  const int feat = 16 * t3 + 4 * g;
+
+  // this wave's float4 of g and of z3 per lane, fetched one tile ahead into registers
+  float4 g4n = make_float4(0.f, 0.f, 0.f, 0.f), z4n = g4n;
+  auto in_issue = [&](int tile) {
+    const long p = min((long)tile * 32 + 16 * b3 + li, A.P - 1);
+    g4n = *reinterpret_cast<const float4*>(A.g + p * 64 + feat);
+    z4n = *reinterpret_cast<const float4*>(A.z3 + p * 64 + feat);
+  };
+  if ((int)blockIdx.x < A.ntiles) in_issue(blockIdx.x);
+  lds_barrier();                               // W1^T, vectors and zeroed accumulators are in LDS
+
+  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    const int next_tile = tile + gridDim.x;
+    const long p0 = (long)tile * 32;
+    const long pt3 = p0 + 16 * b3 + li;
+    const bool live3 = pt3 < A.P;
+    const long off3 = min(pt3, A.P - 1) * 64 + feat;
+    // d2 of this wave's hidden slice (both blocks, both tiles): needed after three barriers, fetched now
+    float4 dd[2][2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        dd[blk][t] = *reinterpret_cast<const float4*>(A.d2 + min(p0 + 16 * blk + li, A.P - 1) * 256 + 16 * (2 * w + t) + 4 * g);
+
+    // ---- last-layer adjoint: dropout, LayerNorm, post-activation ----
+    const float4 g4 = g4n, z4 = z4n;
+    float s4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (A.drop2.on()) drop_scale4(A.drop2, (uint64_t)(pt3 * 64 + feat), s4);
+    const float tz[4] = {z4.x * s4[0], z4.y * s4[1], z4.z * s4[2], z4.w * s4[3]};
+    float gy[4] = {g4.x, g4.y, g4.z, g4.w};
+    if (!live3) { gy[0] = gy[1] = gy[2] = gy[3] = 0.f; }
+    float dz[4], dzb;
+    if (A.layer_norm) {
+      float sum = (tz[0] + tz[1]) + (tz[2] + tz[3]);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mw = sum * (1.f / 16.f);
+      float m2 = (tz[0] - mw) * (tz[0] - mw) + (tz[1] - mw) * (tz[1] - mw) + (tz[2] - mw) * (tz[2] - mw) + (tz[3] - mw) * (tz[3] - mw);
+      m2 += __shfl_xor(m2, 16, 64);
+      m2 += __shfl_xor(m2, 32, 64);
+      if (g == 0) *reinterpret_cast<float2*>(stat1 + ((b3 * 4 + t3) * 16 + li) * 2) = make_float2(mw, m2);
+      lds_barrier();                                                                  // A
+      float mws[4], m2s = 0.f, mean = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float2 s2 = *reinterpret_cast<const float2*>(stat1 + ((b3 * 4 + t) * 16 + li) * 2);
+        mws[t] = s2.x; m2s += s2.y; mean += s2.x;
+      }
+      mean *= 0.25f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) m2s += 16.f * (mws[t] - mean) * (mws[t] - mean);
+      const float rstd = rsqrtf(m2s * (1.f / 64.f) + A.eps);
+      const float4 gm = *reinterpret_cast<const float4*>(vec + feat);
+      const float4 bt = *reinterpret_cast<const float4*>(vec + 64 + feat);
+      const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+      float xh[4], dxh[4], s1 = 0.f, s2 = 0.f, am = 0.f, dgm[4], dbt[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xh[k] = (tz[k] - mean) * rstd;
+        float dy = gy[k];
+        if (A.post_act) dy *= dact_f(A.post_act, xh[k] * gmv[k] + btv[k]);
+        dgm[k] = dy * xh[k];
+        dbt[k] = dy;
+        dxh[k] = dy * gmv[k];
+        s1 += dxh[k];
+        s2 += dxh[k] * xh[k];
+        am = fmaxf(am, fabsf(dxh[k]));
+      }
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      am = fmaxf(am, __shfl_xor(am, 16, 64)); am = fmaxf(am, __shfl_xor(am, 32, 64));
+      if (g == 0) *reinterpret_cast<float4*>(stat2 + ((b3 * 4 + t3) * 16 + li) * 4) = make_float4(s1, s2, am, rstd);
+      // gamma / beta gradients: sum over the 16 points of the block, one writer per (block, feature)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { dgm[k] = row_sum15(dgm[k]); dbt[k] = row_sum15(dbt[k]); }
+      if (li == 15) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc_dg[b3 * 64 + feat + k] += dgm[k]; acc_dbt[b3 * 64 + feat + k] += dbt[k]; }
+      }
+      lds_barrier();                                                                  // B
+      float S1 = 0.f, S2 = 0.f, AM = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 q = *reinterpret_cast<const float4*>(stat2 + ((b3 * 4 + t) * 16 + li) * 4);
+        S1 += q.x; S2 += q.y; AM = fmaxf(AM, q.z);
+      }
+      S1 *= (1.f / 64.f); S2 *= (1.f / 64.f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dz[k] = rstd * (dxh[k] - S1 - xh[k] * S2) * s4[k];
+      // bound of |dz3| over the block (identical in the four waves of the block): |xhat| <= sqrt(63) < 8
+      dzb = wave_max(rstd * (AM + fabsf(S1) + 8.f * fabsf(S2)) * A.drop2.scale);
+    } else {
+      float am = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { dz[k] = gy[k] * dact_f(A.post_act, tz[k]) * s4[k]; am = fmaxf(am, fabsf(dz[k])); }
+      am = wave_max(am);
+      if (g == 0 && li == 0) stat2[(b3 * 4 + t3) * 64] = am;
+      lds_barrier();                                                                  // B (A is not needed)
+      float AM = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) AM = fmaxf(AM, stat2[(b3 * 4 + t) * 64]);
+      dzb = AM;
+    }
+    if (live3) *reinterpret_cast<float4*>(A.dz3 + off3) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    {
+      float b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) b[k] = row_sum15(live3 ? dz[k] : 0.f);
+      if (li == 15) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc_db3[b3 * 64 + feat + k] += b[k];
+      }
+    }
+    // dz3 -> B fragments: (block b3, half ks = t3 >> 1); this wave fills the 8-byte half (t3 & 1) of every lane's
+    // 16 bytes.  The scale comes from the block bound dzb, which the four waves of a block computed identically.
+    {
+      float sdz, sdzi;
+      h2_scale(dzb, 0, sdz, sdzi);
+      uint2 hi, lo;
+      h2_split4(dz[0] * sdz, dz[1] * sdz, dz[2] * sdz, dz[3] * sdz, hi, lo);
+      char* dst = smem + FB_DZBUF + ((b3 * 2 + (t3 >> 1)) * 2) * 1024 + l * 16 + (t3 & 1) * 8;
+      *reinterpret_cast<uint2*>(dst) = hi;
+      *reinterpret_cast<uint2*>(dst + 1024) = lo;
+      if (t3 == 0 && l == 0) info[b3] = dzb;
+    }
+    lds_barrier();                                                                    // C: dz3 fragments + bounds in LDS
+    if (next_tile < A.ntiles) in_issue(next_tile);
+
+    float inv_a[2], s_du2[2], inv_b[2], s_du1[2], inv_c[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+      const float bz = uni(info[blk]);
+      float a, ai;
+      h2_scale(bz, 0, a, ai);
+      inv_a[blk] = uni(ai * winv3);
+      const float b2 = c3t * bz * A.dmax;
+      h2_scale(b2, 0, a, ai);
+      s_du2[blk] = uni(a); inv_b[blk] = uni(ai * winv2);
+      const float b1 = c2t * b2 * A.dmax;
+      h2_scale(b1, 0, a, ai);
+      s_du1[blk] = uni(a); inv_c[blk] = uni(ai * winv1);
+    }
+
+    // ---- du2 = (W3^T dz3) * d2: this wave's 32 hidden rows ----
+    float4 d1v[2][2];
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const char* zb = smem + FB_DZBUF + (blk * 2) * 2048 + l * 16;
+      const f16x8 zh0 = *reinterpret_cast<const f16x8*>(zb), zl0 = *reinterpret_cast<const f16x8*>(zb + 1024);
+      const f16x8 zh1 = *reinterpret_cast<const f16x8*>(zb + 2048), zl1 = *reinterpret_cast<const f16x8*>(zb + 3072);
+      const long pt = p0 + 16 * blk + li;
+      float hv[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        const f16x8 w3l0 = *reinterpret_cast<const f16x8*>(smem + FB_W3L + (w * 4 + 2 * t) * 1024 + l * 16);
+        const f16x8 w3l1 = *reinterpret_cast<const f16x8*>(smem + FB_W3L + (w * 4 + 2 * t + 1) * 1024 + l * 16);
+        acc = h2_mfma32(w3h[t][0], w3l0, zh0, zl0, acc);
+        acc = h2_mfma32(w3h[t][1], w3l1, zh1, zl1, acc);
+        const int hid = 16 * (2 * w + t) + 4 * g;
+        const float4 d = dd[blk][t];
+        const float u[4] = {acc[0] * inv_a[blk] * d.x, acc[1] * inv_a[blk] * d.y, acc[2] * inv_a[blk] * d.z, acc[3] * inv_a[blk] * d.w};
+        if (pt < A.P) {
+          *reinterpret_cast<float4*>(A.du2 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bsum[4 * t + r] += u[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[4 * t + r] = u[r] * s_du2[blk];
+      }
+      ff_put_frag(smem + FB_DUBUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = row_sum15(bsum[i]);
+    if (li == 15) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc_db2[16 * (2 * w + (i >> 2)) + 4 * g + (i & 3)] += bsum[i];
+    }
+    // d1 of the same slice for the next layer (issued here, not earlier: registers)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        d1v[blk][t] = *reinterpret_cast<const float4*>(A.d1 + min(p0 + 16 * blk + li, A.P - 1) * 256 + 16 * (2 * w + t) + 4 * g);
+    lds_barrier();                                                                    // D: du2 slices in LDS
+
+    // ---- du1 = (W2^T du2) * d1 ----
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+    {
+      f32x4v acc[2][2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        acc[blk][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; acc[blk][1] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kap = 0; kap < 8; ++kap) {
+          const char* hb = smem + FB_DUBUF + ((blk * 8 + kap) * 2) * 1024 + l * 16;
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(hb), bl = *reinterpret_cast<const f16x8*>(hb + 1024);
+          acc[blk][0] = h2_mfma32(w2h[0][kap], w2l[0][kap], bh, bl, acc[blk][0]);
+          acc[blk][1] = h2_mfma32(w2h[1][kap], w2l[1][kap], bh, bl, acc[blk][1]);
+        }
+      }
+      lds_barrier();                                                                  // D': every wave has read the du2 slices
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const long pt = p0 + 16 * blk + li;
+        float hv[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int hid = 16 * (2 * w + t) + 4 * g;
+          const float4 d = d1v[blk][t];
+          const float u[4] = {acc[blk][t][0] * inv_b[blk] * d.x, acc[blk][t][1] * inv_b[blk] * d.y,
+                              acc[blk][t][2] * inv_b[blk] * d.z, acc[blk][t][3] * inv_b[blk] * d.w};
+          if (pt < A.P) {
+            *reinterpret_cast<float4*>(A.du1 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bsum[4 * t + r] += u[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[4 * t + r] = u[r] * s_du1[blk];
+        }
+        ff_put_frag(smem + FB_DU1BUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = row_sum15(bsum[i]);
+    if (li == 15) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc_db1[16 * (2 * w + (i >> 2)) + 4 * g + (i & 3)] += bsum[i];
+    }
+    lds_barrier();                                                                    // E: du1 slices in LDS
+
+    // ---- dx = W1^T du1: feature tile t3 of point block b3 ----
+    if (A.dx) {
+      f32x4v acc3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kap = 0; kap < 8; ++kap) {
+        const char* wb = smem + FB_W1T + (t3 * 8 + kap) * 2048 + l * 16;
+        const char* hb = smem + FB_DU1BUF + ((b3 * 8 + kap) * 2) * 1024 + l * 16;
+        acc3 = h2_mfma32(*reinterpret_cast<const f16x8*>(wb), *reinterpret_cast<const f16x8*>(wb + 1024),
+                         *reinterpret_cast<const f16x8*>(hb), *reinterpret_cast<const f16x8*>(hb + 1024), acc3);
+      }
+      if (live3) *reinterpret_cast<float4*>(A.dx + off3) = make_float4(acc3[0] * inv_c[b3], acc3[1] * inv_c[b3], acc3[2] * inv_c[b3], acc3[3] * inv_c[b3]);
+    }
+  }
+  // ---- per-workgroup sums out ----
+  lds_barrier();
+  {
+    float* part = A.part + (long)blockIdx.x * FFB_PART;
+    for (int i = tid; i < FFB_PART; i += 64 * FF_WAVES) {
+      float v;
+      if (i < 512) v = acc_db1[i];                                   // db1, db2
+      else if (i < 576) v = acc_db3[i - 512] + acc_db3[64 + i - 512];
+      else if (i < 640) v = acc_dg[i - 576] + acc_dg[64 + i - 576];
+      else v = acc_dbt[i - 640] + acc_dbt[64 + i - 640];
+      part[i] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 bool ff3_fused_ok(const rpde_ff_params* p, long P) {
   if (const char* e = getenv("RPDE_FUSED_FF")) if (e[0] == '0') return false;
@@ -449,6 +849,41 @@ int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual
   if (train) hipLaunchKernelGGL(k_ff3_fwd_h2<true>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
   else hipLaunchKernelGGL(k_ff3_fwd_h2<false>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
   RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+size_t ff3_fused_bwd_part_floats() { return (size_t)1024 * FFB_PART; }
+
+// prep + the fused kernel: dz3 [P,64], du2, du1 [P,256], dx [P,64] (may be null), part [grid][704]; returns the grid
+int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, const float* z_last, const float* grad_out,
+                         float* dz3, float* du2, float* du1, float* dx, float* part, int* grid_out, long P, void* ws,
+                         hipStream_t st) {
+  char* img = static_cast<char*>(ws);
+  float* consts = reinterpret_cast<float*>(img + FF_IMG_BYTES);
+  hipLaunchKernelGGL(k_ff3_prep_bwd, dim3(1), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], img, consts);
+  RPDE_LAUNCH_CHECK();
+  FF3B A;
+  memset(&A, 0, sizeof(A));
+  A.g = grad_out; A.z3 = z_last; A.d1 = ds[0]; A.d2 = ds[1];
+  A.dz3 = dz3; A.du2 = du2; A.du1 = du1; A.dx = dx;
+  A.wimg = img; A.consts = consts; A.gamma = p->ln_gamma; A.beta = p->ln_beta; A.part = part;
+  A.P = P; A.layer_norm = p->layer_norm; A.eps = p->ln_eps; A.post_act = p->post_act;
+  {
+    uint64_t z = p->seed + 0x9E3779B97F4A7C15ull * (uint64_t)(2 + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    A.drop2 = make_drop(p->dropout_p, z ^ (z >> 31));
+  }
+  A.dmax = 1.13f * A.drop2.scale;          // |gelu'| <= 1.129, times the dropout scale folded into d
+  A.ntiles = (int)((P + 31) / 32);
+  int dev = 0, cus = 256;
+  RPDE_HIP(hipGetDevice(&dev));
+  RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (cus > 1024) cus = 1024;
+  const int grid = A.ntiles < cus ? A.ntiles : cus;
+  hipLaunchKernelGGL(k_ff3_bwd_h2, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
+  RPDE_LAUNCH_CHECK();
+  *grid_out = grid;
   return RPDE_OK;
 }
 
