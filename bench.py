@@ -291,6 +291,7 @@ def main():
         bucket.all_reduce_mean()
         if world > 1 and timed >= 0:
             ar_ev[timed][1].record()
+        bucket.detach_untouched()
         opt.step()
         losses[i].copy_(loss.detach())         # device-side bookkeeping, no per-step host sync
 

@@ -128,8 +128,8 @@ constexpr int FF_H2BUF = FF_HBUF + 32768;         // the same for h2            
 constexpr int FF_W3 = FF_H2BUF + 32768;           // [4 tile][8 kappa][hi|lo][1 KB]: all of W3                    = 64 KB
 constexpr int FF_VEC = FF_W3 + 65536;             // b1[256] b2[256] b3[64] gamma[64] beta[64] floats             = 2816 B
 constexpr int FF_STAT = FF_VEC + 2816;            // [2 blk][4 tile][16 points][mean, M2] floats                  =  1 KB
-constexpr int FF_INFO = FF_STAT + 1024;           // [2 blk] floats: maximum of the input block
-constexpr int FF_LDS = FF_INFO + 64;
+constexpr int FF_INFO = FF_STAT + 1024;           // [2 parity][2 blk][16 points] floats: maximum of each input point
+constexpr int FF_LDS = FF_INFO + 256;
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() would also wait for every outstanding global
 // store (the h / d tensors a training forward writes) several times per tile
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
     __builtin_amdgcn_global_load_lds((glb_ptr)(q + 32), (lds_ptr)(dst + 2048), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_ptr)(q + 36), (lds_ptr)(dst + 3072), 16, 0, 0);
   };
-  auto s_convert = [&]() {
+  auto s_convert = [&](int par) {
     float4 sn[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) sn[i] = *reinterpret_cast<const float4*>(smem + FF_RAW + w * 4096 + i * 1024 + l * 16);
@@ -224,7 +224,11 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
       asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(sn[i].x), "v"(sn[i].y));
       asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(sn[i].z), "v"(sn[i].w));
     }
-    m = wave_max(m);
+    // one scale per POINT (a column of the B operand): the four lanes that hold a point's 64 channels agree on its
+    // maximum.  Points of very different magnitude inside a block then keep their own relative precision, which
+    // the per-point LayerNorm at the end would otherwise expose
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
     float sc, iv;
     h2_scale(m, 0, sc, iv);
     char* dst = smem + FF_SBUF + (w * 2) * 2048 + l * 16;
@@ -234,12 +238,12 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
                           sn[2 * ks + 1].x * sc, sn[2 * ks + 1].y * sc, sn[2 * ks + 1].z * sc, sn[2 * ks + 1].w * sc};
       ff_put_frag(dst + ks * 2048, v);
     }
-    if (l == 0) info[w] = m;
+    if (g == 0) info[(par * 2 + w) * 16 + li] = m;
   };
   if (w < 2 && (int)blockIdx.x < A.ntiles) {
     s_issue(blockIdx.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_convert();
+    s_convert(0);
   }
   // role in the last layer: output tile t3 (16 features) of point block b3
   const int t3 = w & 3, b3 = w >> 2;
@@ -249,7 +253,8 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
   const int stamp_w = w == 0 ? 0 : (w == 3 ? 1 : 2);
   int stamp_t = -4;                      // skip the first four tiles (cold caches)
 #endif
-  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+  int par = 0;
+  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x, par ^= 1) {
     FFSTAMP(0);
     lds_barrier();                         // B0: input fragments of this tile (and, first time, W3 / vectors) are in LDS
     FFSTAMP(1);
@@ -257,21 +262,20 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
     if (w < 2 && next_tile < A.ntiles) s_issue(next_tile);
     const long p0 = (long)tile * 32;
 
-    // per 16-point block: scales of x (exact maximum), h1 and h2 (bounds); wave-uniform
-    float inv1[2], sh1[2], inv2[2], sh2[2], inv3[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      const float smax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(info[blk])));
+    // per point (= per lane column): scales of x (its maximum), of h1 and h2 (bounds derived from it), recomputed
+    // where needed from the point's maximum rather than kept in registers
+    auto scales = [&](int blk, float& inv1, float& sh1, float& inv2, float& sh2, float& inv3) {
+      const float smax = info[(par * 2 + blk) * 16 + li];      // (the other parity is being written for the next tile)
       float sx, sxi, a, ai;
       h2_scale(smax, 0, sx, sxi);
-      inv1[blk] = sxi * winv1;
+      inv1 = sxi * winv1;
       const float bound1 = fmaf(c1, smax, b1max) * A.drop[0].scale;
       h2_scale(bound1, 0, a, ai);
-      sh1[blk] = a; inv2[blk] = ai * winv2;
+      sh1 = a; inv2 = ai * winv2;
       const float bound2 = fmaf(c2, bound1, b2max) * A.drop[1].scale;
       h2_scale(bound2, 0, a, ai);
-      sh2[blk] = a; inv3[blk] = ai * winv3;
-    }
+      sh2 = a; inv3 = ai * winv3;
+    };
 
     // (tried and dropped, same-box A/B: issuing the accumulator chains of a layer interleaved (no faster: the phases
     //  are bound by the vector work of the activation; the extra live fragments spilled), and a two-barrier software
@@ -286,6 +290,8 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
       const f16x8 xh0 = *reinterpret_cast<const f16x8*>(sb), xl0 = *reinterpret_cast<const f16x8*>(sb + 1024);
       const f16x8 xh1 = *reinterpret_cast<const f16x8*>(sb + 2048), xl1 = *reinterpret_cast<const f16x8*>(sb + 3072);
       const long pt = p0 + 16 * blk + li;
+      float inv1, sh1, u0, u1, u2;
+      scales(blk, inv1, sh1, u0, u1, u2);
       float hv[8];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -294,13 +300,13 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
         acc = h2_mfma32(w1h[t][1], w1l[t][1], xh1, xl1, acc);
         float h[4], d[4];
         const int hid = 16 * (2 * w + t) + 4 * g;
-        ff_act4(acc, inv1[blk], *reinterpret_cast<const float4*>(vec + hid), A.drop[0], (uint64_t)(pt * 256 + hid), h, d);
+        ff_act4(acc, inv1, *reinterpret_cast<const float4*>(vec + hid), A.drop[0], (uint64_t)(pt * 256 + hid), h, d);
         if (TRAIN && pt < A.P) {
           *reinterpret_cast<float4*>(A.h1 + pt * 256 + hid) = make_float4(h[0], h[1], h[2], h[3]);
           *reinterpret_cast<float4*>(A.d1 + pt * 256 + hid) = make_float4(d[0], d[1], d[2], d[3]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[4 * t + r] = h[r] * sh1[blk];
+        for (int r = 0; r < 4; ++r) hv[4 * t + r] = h[r] * sh1;
       }
       ff_put_frag(smem + FF_HBUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
     }
@@ -326,18 +332,20 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
         acc[1] = h2_mfma32(w2h[1][kap], w2l[1][kap], bh, bl, acc[1]);
       }
       const long pt = p0 + 16 * blk + li;
+      float u0, u1, inv2, sh2, u2;
+      scales(blk, u0, u1, inv2, sh2, u2);
       float hv[8];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         float h[4], d[4];
         const int hid = 16 * (2 * w + t) + 4 * g;
-        ff_act4(acc[t], inv2[blk], *reinterpret_cast<const float4*>(vec + 256 + hid), A.drop[1], (uint64_t)(pt * 256 + hid), h, d);
+        ff_act4(acc[t], inv2, *reinterpret_cast<const float4*>(vec + 256 + hid), A.drop[1], (uint64_t)(pt * 256 + hid), h, d);
         if (TRAIN && pt < A.P) {
           *reinterpret_cast<float4*>(A.h2 + pt * 256 + hid) = make_float4(h[0], h[1], h[2], h[3]);
           *reinterpret_cast<float4*>(A.d2 + pt * 256 + hid) = make_float4(d[0], d[1], d[2], d[3]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[4 * t + r] = h[r] * sh2[blk];
+        for (int r = 0; r < 4; ++r) hv[4 * t + r] = h[r] * sh2;
       }
       ff_put_frag(smem + FF_H2BUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
     }
@@ -358,13 +366,15 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
       // the DMA of the next input tile was issued before this tile's stores (16 when training): it is older than the
       // eight youngest of them, so vmcnt(8) covers it without waiting for all stores to be acknowledged
       if (TRAIN) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      s_convert();
+      s_convert(par ^ 1);
     }
     float v[4];
     {
       const float4 bb = *reinterpret_cast<const float4*>(vec + 512 + 16 * t3 + 4 * g);
-      v[0] = fmaf(acc3[0], inv3[b3], bb.x); v[1] = fmaf(acc3[1], inv3[b3], bb.y);
-      v[2] = fmaf(acc3[2], inv3[b3], bb.z); v[3] = fmaf(acc3[3], inv3[b3], bb.w);
+      float u0, u1, u2, u3, inv3;
+      scales(b3, u0, u1, u2, u3, inv3);
+      v[0] = fmaf(acc3[0], inv3, bb.x); v[1] = fmaf(acc3[1], inv3, bb.y);
+      v[2] = fmaf(acc3[2], inv3, bb.z); v[3] = fmaf(acc3[3], inv3, bb.w);
       if (TRAIN && pt3 < A.P) *reinterpret_cast<float4*>(A.z3 + off3) = make_float4(v[0], v[1], v[2], v[3]);
       if (A.drop[2].on()) {
         float s4[4];
@@ -496,8 +506,8 @@ constexpr int FB_VEC = FB_W1T + 65536;             // gamma[64] beta[64]
 constexpr int FB_ACC = FB_VEC + 512;               // db1[256] db2[256] db3[2][64] dgamma[2][64] dbeta[2][64] = 3584 B
 constexpr int FB_STAT1 = FB_ACC + 3584;            // [2 blk][4 tile][16 points][mean, M2]                    = 1 KB
 constexpr int FB_STAT2 = FB_STAT1 + 1024;          // [2 blk][4 tile][16 points][s1, s2, amax, -]             = 2 KB
-constexpr int FB_INFO = FB_STAT2 + 2048;           // [2 blk] bound of |dz3|
-constexpr int FB_LDS = FB_INFO + 64;
+constexpr int FB_INFO = FB_STAT2 + 2048;           // [2 blk][16 points] bound of |dz3|
+constexpr int FB_LDS = FB_INFO + 128;
 
 // sum over the 16 lanes of a row (one point block), valid in lane 15 of the row
 __device__ __forceinline__ float row_sum15(float v) {
@@ -639,17 +649,18 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) dz[k] = rstd * (dxh[k] - S1 - xh[k] * S2) * s4[k];
       // bound of |dz3| over the block (identical in the four waves of the block): |xhat| <= sqrt(63) < 8
-      dzb = wave_max(rstd * (AM + fabsf(S1) + 8.f * fabsf(S2)) * A.drop2.scale);
+      // bound of this POINT's |dz3| (identical in the four waves that share the point): |xhat| <= sqrt(63) < 8
+      dzb = rstd * (AM + fabsf(S1) + 8.f * fabsf(S2)) * A.drop2.scale;
     } else {
       float am = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { dz[k] = gy[k] * dact_f(A.post_act, tz[k]) * s4[k]; am = fmaxf(am, fabsf(dz[k])); }
-      am = wave_max(am);
-      if (g == 0 && li == 0) stat2[(b3 * 4 + t3) * 64] = am;
+      am = fmaxf(am, __shfl_xor(am, 16, 64)); am = fmaxf(am, __shfl_xor(am, 32, 64));
+      if (g == 0) stat2[((b3 * 4 + t3) * 16 + li) * 4] = am;
       lds_barrier();                                                                  // B (A is not needed)
       float AM = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) AM = fmaxf(AM, stat2[(b3 * 4 + t) * 64]);
+      for (int t = 0; t < 4; ++t) AM = fmaxf(AM, stat2[((b3 * 4 + t) * 16 + li) * 4]);
       dzb = AM;
     }
     if (live3) *reinterpret_cast<float4*>(A.dz3 + off3) = make_float4(dz[0], dz[1], dz[2], dz[3]);
@@ -663,7 +674,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       }
     }
     // dz3 -> B fragments: (block b3, half ks = t3 >> 1); this wave fills the 8-byte half (t3 & 1) of every lane's
-    // 16 bytes.  The scale comes from the block bound dzb, which the four waves of a block computed identically.
+    // 16 bytes.  One scale per point, from the bound dzb that the four waves sharing the point computed identically.
     {
       float sdz, sdzi;
       h2_scale(dzb, 0, sdz, sdzi);
@@ -672,26 +683,24 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       char* dst = smem + FB_DZBUF + ((b3 * 2 + (t3 >> 1)) * 2) * 1024 + l * 16 + (t3 & 1) * 8;
       *reinterpret_cast<uint2*>(dst) = hi;
       *reinterpret_cast<uint2*>(dst + 1024) = lo;
-      if (t3 == 0 && l == 0) info[b3] = dzb;
+      if (t3 == 0 && g == 0) info[b3 * 16 + li] = dzb;
     }
     lds_barrier();                                                                    // C: dz3 fragments + bounds in LDS
     if (next_tile < A.ntiles) in_issue(next_tile);
 
-    float inv_a[2], s_du2[2], inv_b[2], s_du1[2], inv_c[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
-      const float bz = uni(info[blk]);
+    // per point: scale of dz3 (its bound), of du2 and du1 (bounds derived from it); recomputed at each use
+    auto bscales = [&](int blk, float& inv_a, float& s_du2, float& inv_b, float& s_du1, float& inv_c) {
+      const float bz = info[blk * 16 + li];
       float a, ai;
       h2_scale(bz, 0, a, ai);
-      inv_a[blk] = uni(ai * winv3);
+      inv_a = ai * winv3;
       const float b2 = c3t * bz * A.dmax;
       h2_scale(b2, 0, a, ai);
-      s_du2[blk] = uni(a); inv_b[blk] = uni(ai * winv2);
+      s_du2 = a; inv_b = ai * winv2;
       const float b1 = c2t * b2 * A.dmax;
       h2_scale(b1, 0, a, ai);
-      s_du1[blk] = uni(a); inv_c[blk] = uni(ai * winv1);
-    }
+      s_du1 = a; inv_c = ai * winv1;
+    };
 
     // ---- du2 = (W3^T dz3) * d2: this wave's 32 hidden rows ----
     float4 d1v[2][2];
@@ -702,6 +711,8 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       const f16x8 zh0 = *reinterpret_cast<const f16x8*>(zb), zl0 = *reinterpret_cast<const f16x8*>(zb + 1024);
       const f16x8 zh1 = *reinterpret_cast<const f16x8*>(zb + 2048), zl1 = *reinterpret_cast<const f16x8*>(zb + 3072);
       const long pt = p0 + 16 * blk + li;
+      float inv_a, s_du2, q0, q1, q2;
+      bscales(blk, inv_a, s_du2, q0, q1, q2);
       float hv[8];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -712,14 +723,14 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
         acc = h2_mfma32(w3h[t][1], w3l1, zh1, zl1, acc);
         const int hid = 16 * (2 * w + t) + 4 * g;
         const float4 d = dd[blk][t];
-        const float u[4] = {acc[0] * inv_a[blk] * d.x, acc[1] * inv_a[blk] * d.y, acc[2] * inv_a[blk] * d.z, acc[3] * inv_a[blk] * d.w};
+        const float u[4] = {acc[0] * inv_a * d.x, acc[1] * inv_a * d.y, acc[2] * inv_a * d.z, acc[3] * inv_a * d.w};
         if (pt < A.P) {
           *reinterpret_cast<float4*>(A.du2 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) bsum[4 * t + r] += u[r];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[4 * t + r] = u[r] * s_du2[blk];
+        for (int r = 0; r < 4; ++r) hv[4 * t + r] = u[r] * s_du2;
       }
       ff_put_frag(smem + FB_DUBUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
     }
@@ -757,20 +768,22 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         const long pt = p0 + 16 * blk + li;
+        float q0, q1, inv_b, s_du1, q2;
+        bscales(blk, q0, q1, inv_b, s_du1, q2);
         float hv[8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int hid = 16 * (2 * w + t) + 4 * g;
           const float4 d = d1v[blk][t];
-          const float u[4] = {acc[blk][t][0] * inv_b[blk] * d.x, acc[blk][t][1] * inv_b[blk] * d.y,
-                              acc[blk][t][2] * inv_b[blk] * d.z, acc[blk][t][3] * inv_b[blk] * d.w};
+          const float u[4] = {acc[blk][t][0] * inv_b * d.x, acc[blk][t][1] * inv_b * d.y,
+                              acc[blk][t][2] * inv_b * d.z, acc[blk][t][3] * inv_b * d.w};
           if (pt < A.P) {
             *reinterpret_cast<float4*>(A.du1 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bsum[4 * t + r] += u[r];
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[4 * t + r] = u[r] * s_du1[blk];
+          for (int r = 0; r < 4; ++r) hv[4 * t + r] = u[r] * s_du1;
         }
         ff_put_frag(smem + FB_DU1BUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
       }
@@ -793,7 +806,9 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
         acc3 = h2_mfma32(*reinterpret_cast<const f16x8*>(wb), *reinterpret_cast<const f16x8*>(wb + 1024),
                          *reinterpret_cast<const f16x8*>(hb), *reinterpret_cast<const f16x8*>(hb + 1024), acc3);
       }
-      if (live3) *reinterpret_cast<float4*>(A.dx + off3) = make_float4(acc3[0] * inv_c[b3], acc3[1] * inv_c[b3], acc3[2] * inv_c[b3], acc3[3] * inv_c[b3]);
+      float q0, q1, q2, q3, inv_c;
+      bscales(b3, q0, q1, q2, q3, inv_c);
+      if (live3) *reinterpret_cast<float4*>(A.dx + off3) = make_float4(acc3[0] * inv_c, acc3[1] * inv_c, acc3[2] * inv_c, acc3[3] * inv_c);
     }
   }
   // ---- per-workgroup sums out ----

@@ -56,12 +56,14 @@ def run(dims: int, argv=None):
         top = max(int(r) for r in dict(args.dataset.resolutions))
         val_set = markov_pairs({top: int(args.dataset.n_val)}, dims, seed + 50000)
         test_set = markov_pairs({top: int(args.dataset.n_test)}, dims, seed + 60000)
+    # training: equal rank slices of whole global batches; validation / test: every sample once (ragged rank shares)
     mk = lambda ds, shuffle: ResolutionGroupedDataLoader(ds, bs, shuffle=shuffle, seed=seed, rank=rank,  # noqa: E731
-                                                         world_size=world, verbose=rank == 0)
+                                                         world_size=world, verbose=rank == 0, drop_last=shuffle)
     train_loader, val_loader, test_loader = mk(train_set, True), mk(val_set, False), mk(test_set, False)
 
     torch.manual_seed(seed)                                   # same initial weights on every rank
     model = instantiate(args.model).to(device)
+    torch.manual_seed(seed + 1 + rank)                        # dropout seeds are drawn from this stream: one per rank
     ckpt = args.dataset.get("saved_checkpoint_path")
     if ckpt:
         state = torch.load(ckpt, map_location=device, weights_only=True)
@@ -84,14 +86,54 @@ def run(dims: int, argv=None):
                                 use_normalizer=bool(args.training.use_normalizer), epochs=int(args.training.epochs),
                                 device=device)
     torch.cuda.synchronize()
-    test_l2 = evaluate(model, test_loader, y_normalizer=y_normalizer, device=device)
+    test_l2 = evaluate(model, test_loader, normalization_type="simple", y_normalizer=y_normalizer, device=device)
     if rank == 0:
         print(json.dumps({"train_seconds": round(time.time() - t0, 3), "final_train_loss": loss_hist[-1],
                           "final_val_loss": val_hist[-1], "test_rel_l2": test_l2}), flush=True)
+
+    # ---- the reference's post-training sequence: every resolution [32, .., max] (main_2d.py:287, main_1d.py:250),
+    # ---- and in 1-D the autoregressive rollout (main_1d.py:272; utils/autoregressive_step.py:284-309)
+    from utils.resize_utils import evaluate_all_resolutions, to_resolution
+    tx = torch.stack([test_set[i][0] for i in range(len(test_set))])
+    ty = torch.stack([test_set[i][1] for i in range(len(test_set))])
+    top_res = int(tx.shape[-1])
+    how = str(args.dataset.get("evaluation_type", "naive_downsample"))
+    dec = (lambda t: y_normalizer.decode(t, device=device)) if y_normalizer is not None else None   # noqa: E731
+    ty_phys = dec(ty.to(device)).cpu() if dec else ty
+    resolution_results = evaluate_all_resolutions(model, tx, ty_phys, max_resolution=top_res, min_resolution=min(32, top_res),
+                                                  how=how, batch_size=bs, y_decode=dec, device=device)
+    rollout_results = None
+    if dims == 1 and not args.dataset.get("dataset_params"):
+        from utils.autoregressive_step import perform_rollout_1d, rollout_loss
+        from utils.synthetic import advance
+        steps = int(args.dataset.get("rollout_steps", 4))
+        traj = [tx[rank::world, 0]]
+        for _ in range(steps):
+            traj.append(advance(traj[-1], 1))
+        traj = torch.stack(traj, dim=1).to(device)                           # [n, steps+1, res]
+        acc = torch.zeros(len(resolution_results), 2, dtype=torch.float64, device=device)
+        for k, res in enumerate(resolution_results):
+            tr = to_resolution(traj, res, "naive_downsample")
+            if tr.shape[0]:
+                pred = perform_rollout_1d(model.eval(), tr[:, 0], steps, device=device)
+                acc[k, 0] += rollout_loss(pred, tr) * tr.shape[0]
+                acc[k, 1] += tr.shape[0]
+        if world > 1:
+            dist.all_reduce(acc)
+        rollout_results = {res: (float(acc[k, 0] / acc[k, 1]) if float(acc[k, 1]) > 0 else float("nan"))
+                           for k, res in enumerate(resolution_results)}
+    if rank == 0:
+        print(json.dumps({"evaluation_type": how, "resolution_rel_l2": {str(k): v for k, v in resolution_results.items()}}),
+              flush=True)
+        if rollout_results is not None:
+            print(json.dumps({"rollout_rel_l2": {str(k): v for k, v in rollout_results.items()}}), flush=True)
+    run.last = {"test_rel_l2": test_l2, "resolution_rel_l2": resolution_results, "rollout_rel_l2": rollout_results}
+    if rank == 0:
         os.makedirs(args.checkpoint_dir, exist_ok=True)
         path = os.path.join(args.checkpoint_dir, f"{args.project_name}_{dims}d.pt")
         torch.save({"model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
-                    "loss_history": loss_hist, "val_loss_history": val_hist, "l2_loss": test_l2}, path)
+                    "loss_history": loss_hist, "val_loss_history": val_hist, "l2_loss": test_l2,
+                    "resolution_rel_l2": resolution_results}, path)
         print(json.dumps({"checkpoint": path}), flush=True)
     if world > 1:
         dist.barrier()

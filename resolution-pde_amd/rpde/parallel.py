@@ -29,14 +29,19 @@ class FlatGradBucket:
         padded = [(n + 3) // 4 * 4 for n in sizes]          # 16-byte aligned chunks (complex views need even offsets)
         self.flat = torch.zeros(sum(padded), dtype=torch.float32, device=dev)
         off = 0
-        for p, n, step in zip(self.params, sizes, padded):
+        self._views: List[torch.Tensor] = []
+        self._touched = set()
+        for i, (p, n, step) in enumerate(zip(self.params, sizes, padded)):
             chunk = self.flat[off:off + n]
             if p.is_complex():
-                p.grad = torch.view_as_complex(chunk.view(*p.shape, 2))
+                view = torch.view_as_complex(chunk.view(*p.shape, 2))
             else:
                 if p.dtype != torch.float32:
                     raise TypeError(f"expected fp32 / complex64 parameters, got {p.dtype}")
-                p.grad = chunk.view(p.shape)
+                view = chunk.view(p.shape)
+            self._views.append(view)
+            p.grad = view
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touched.add(i))
             off += step
 
     @property
@@ -44,8 +49,20 @@ class FlatGradBucket:
         return self.flat.numel() * 4
 
     def zero(self) -> None:
-        """replaces optimizer.zero_grad(): keeps the .grad views alive"""
+        """replaces optimizer.zero_grad(): zeroes the bucket and (re)attaches every .grad view"""
         self.flat.zero_()
+        self._touched.clear()
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+
+    def detach_untouched(self) -> None:
+        """call between backward (+ all-reduce) and optimizer.step(): a parameter that took no part in this step's
+        graph (fourier_weight in mode='low-pass', an unused forecast_ff ...) gets grad None, which is what the
+        reference's zero_grad() leaves it with, so AdamW applies neither moments nor weight decay to it.  Every
+        rank runs the same graph, so the sets agree; the next zero() re-attaches the views."""
+        for i, p in enumerate(self.params):
+            if i not in self._touched:
+                p.grad = None
 
     def all_reduce_mean(self) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

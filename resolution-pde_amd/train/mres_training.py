@@ -75,8 +75,13 @@ class ResolutionGroupedSampler(Sampler):
 
 class ResolutionGroupedDataLoader:
     def __init__(self, dataset, batch_size, shuffle=True, num_workers=0, seed: Optional[int] = None,
-                 rank: int = 0, world_size: int = 1, verbose: bool = True):
+                 rank: int = 0, world_size: int = 1, verbose: bool = True, drop_last: Optional[bool] = None):
+        """drop_last (world_size > 1 only; default = ``shuffle``): True for training -- equal rank slices of whole
+        global batches, so that every rank runs the same shapes in the same order beside the gradient all-reduce;
+        False for validation / test -- every sample is used exactly once: rank r takes samples r, r+world, ... of
+        each resolution and keeps its ragged (possibly empty) tail; the caller reduces a sample-weighted sum"""
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
+        self.drop_last = bool(shuffle) if drop_last is None else bool(drop_last)
         self.seed, self.rank, self.world_size = seed, int(rank), int(world_size)
         self.epoch = 0
         if not 0 <= self.rank < self.world_size:
@@ -106,6 +111,9 @@ class ResolutionGroupedDataLoader:
                 rng.shuffle(order)
             if self.world_size == 1:
                 plan += [(res, order[i:i + self.batch_size]) for i in range(0, len(order), self.batch_size)]
+            elif not self.drop_last:
+                mine = order[self.rank::self.world_size]
+                plan += [(res, mine[i:i + self.batch_size]) for i in range(0, len(mine), self.batch_size)]
             else:
                 for i in range(0, len(order) - glob + 1, glob):
                     lo = i + self.rank * self.batch_size
@@ -124,6 +132,9 @@ class ResolutionGroupedDataLoader:
         glob = self.batch_size * self.world_size
         if self.world_size == 1:
             return sum((len(s) + self.batch_size - 1) // self.batch_size for s in self.resolution_groups.values())
+        if not self.drop_last:
+            return sum((len(range(self.rank, len(s), self.world_size)) + self.batch_size - 1) // self.batch_size
+                       for s in self.resolution_groups.values())
         return sum(len(s) // glob for s in self.resolution_groups.values())
 
 

@@ -29,11 +29,15 @@ def _dist_on() -> bool:
 
 
 def _mean_over_ranks(total: torch.Tensor, count: int) -> float:
+    """sum(total) / sum(count) over the ranks; NaN when nothing was counted anywhere (an empty loader is an error
+    of the caller's data split, never a perfect score)"""
     t = torch.stack([total.detach().double().reshape(()), torch.tensor(float(count), dtype=torch.float64,
                                                                        device=total.device)])
     if _dist_on():
         dist.all_reduce(t)
-    return float(t[0] / max(t[1], 1.0))
+    if float(t[1]) == 0.0:
+        return float("nan")
+    return float(t[0] / t[1])
 
 
 def train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=None, use_normalizer=False, time=1,
@@ -56,6 +60,7 @@ def train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=No
             loss = loss_fn(pred_y, batch_y)
             loss.backward()
             bucket.all_reduce_mean()
+            bucket.detach_untouched()          # parameters outside the graph keep grad None, as after zero_grad()
             optimizer.step()
             running += loss.detach()
             n_batches += 1
@@ -72,8 +77,8 @@ def train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=No
                 if use_normalizer and y_normalizer is not None:
                     val_pred = y_normalizer.decode(val_pred, device=device)
                     val_y = y_normalizer.decode(val_y, device=device)
-                vrun += loss_fn(val_pred, val_y)
-                vn += 1
+                vrun += loss_fn(val_pred, val_y) * val_x.shape[0]     # sample-weighted: ranks may hold ragged shares
+                vn += val_x.shape[0]
         avg_val = _mean_over_ranks(vrun, vn)
         val_loss_history.append(avg_val)
 
@@ -93,24 +98,43 @@ def denormalize_data(data, min_val, max_val):
     return data * (max_val - min_val) + min_val
 
 
-def evaluate(model, test_loader, norm_type="simple", y_normalizer=None, min_data=None, max_data=None, min_model=None,
-             max_model=None, time=1, model_type="ffno", device="cuda"):
-    """mean relative L2 over the test batches on de-normalised fields
-    ('simple': y_normalizer.decode; 'minmax': affine from the stored ranges)"""
+def evaluate(model, test_loader,
+             normalization_type='minmax',
+             min_data=None, max_data=None, min_model=None, max_model=None,
+             y_normalizer=None,
+             time=1, model_type='ffno', device='cuda'):
+    """mean relative L2 over the test samples on de-normalised fields; signature, defaults and the ValueError of
+    the reference (train/training.py:93-146).  'minmax': affine from (min_model, max_model); 'simple':
+    y_normalizer.decode.  The mean is sample-weighted (the reference averages batch means: identical for equal
+    batches) and reduced over the ranks."""
     loss_fn = RelativeL2Loss(size_average=True)
     model.eval()
     total = torch.zeros((), device=device)
     n = 0
+    warned = False
     with torch.no_grad():
         for x, y in test_loader:
             x, y = x.to(device), y.to(device)
             pred = model(x)
-            if norm_type == "minmax" and min_model is not None:
-                pred = denormalize_data(pred, min_model, max_model)
-                y = denormalize_data(y, min_model, max_model)
-            elif norm_type == "simple" and y_normalizer is not None:
-                pred = y_normalizer.decode(pred, device=device)
-                y = y_normalizer.decode(y, device=device)
-            total += loss_fn(pred, y)
-            n += 1
-    return _mean_over_ranks(total, n)
+            if normalization_type == 'minmax':
+                if min_model is not None and max_model is not None:
+                    pred = denormalize_data(pred, min_model, max_model)
+                    y = denormalize_data(y, min_model, max_model)
+                elif not warned:
+                    print("Warning: min_model/max_model not provided for minmax normalization")
+                    warned = True
+            elif normalization_type == 'simple':
+                if y_normalizer is not None:
+                    pred = y_normalizer.decode(pred, device=device)
+                    y = y_normalizer.decode(y, device=device)
+                elif not warned:
+                    print("Warning: y_normalizer not provided for simple normalization")
+                    warned = True
+            else:
+                raise ValueError(f"Invalid normalization_type: {normalization_type}. Must be 'minmax' or 'simple'")
+            total += loss_fn(pred, y) * x.shape[0]
+            n += x.shape[0]
+    avg = _mean_over_ranks(total, n)
+    if not _dist_on() or dist.get_rank() == 0:
+        print(f"Test L2 Loss: {avg:.6f}")
+    return avg

@@ -43,21 +43,28 @@ def evaluate_all_resolutions(model, test_x: torch.Tensor, test_y: torch.Tensor, 
                              min_resolution: int = 32, how: str = "naive_downsample", batch_size: int = 16,
                              x_encode: Optional[Callable] = None, y_decode: Optional[Callable] = None,
                              device="cuda") -> Dict[int, float]:
-    """{resolution: mean relative L2 over the test batches}; encode/decode are the x / y normalisers"""
+    """{resolution: mean relative L2 over the test samples}; encode/decode are the x / y normalisers.  With
+    torch.distributed initialised every rank evaluates samples rank, rank + world, ... and the sample-weighted sums
+    are reduced (NaN for a resolution without samples)."""
+    import torch.distributed as dist
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
     model.eval()
     loss_fn = RelativeL2Loss(size_average=True)
     full = test_x.shape[-1]
-    results: Dict[int, float] = {}
-    for res in get_lower_resolutions(max_resolution or full, min_resolution):
-        total = torch.zeros((), device=device)
-        nb = 0
-        for i in range(0, test_x.shape[0], batch_size):
-            x = to_resolution(test_x[i:i + batch_size].to(device), res, how)
-            y = to_resolution(test_y[i:i + batch_size].to(device), res, how)
+    mine_x, mine_y = test_x[rank::world], test_y[rank::world]
+    resolutions = get_lower_resolutions(max_resolution or full, min_resolution)
+    acc = torch.zeros(len(resolutions), 2, dtype=torch.float64, device=device)
+    for k, res in enumerate(resolutions):
+        for i in range(0, mine_x.shape[0], batch_size):
+            x = to_resolution(mine_x[i:i + batch_size].to(device), res, how)
+            y = to_resolution(mine_y[i:i + batch_size].to(device), res, how)
             pred = model(x_encode(x) if x_encode else x)
             if y_decode:
                 pred = y_decode(pred)
-            total += loss_fn(pred, y)
-            nb += 1
-        results[res] = float(total / max(nb, 1))
-    return results
+            acc[k, 0] += loss_fn(pred, y).double() * x.shape[0]
+            acc[k, 1] += x.shape[0]
+    if on:
+        dist.all_reduce(acc)
+    acc = acc.cpu()
+    return {res: (float(acc[k, 0] / acc[k, 1]) if float(acc[k, 1]) > 0 else float("nan")) for k, res in enumerate(resolutions)}

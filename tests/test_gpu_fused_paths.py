@@ -1,0 +1,134 @@
+"""The fused h2 kernels (two-piece f16 arithmetic with dynamic power-of-two scaling: csrc/h2.h,
+fused_spectral.hip, ff_fused.hip) against the per-GEMM split-bf16 path they replace, on the same inputs --
+including inputs whose scale is far from 1 or varies by many orders of magnitude inside one tensor, which is what
+the scaling has to survive (f16 alone has a 5-bit exponent)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _spectral(x, wy, wx, K, g):
+    from rpde import ops
+    xs = x.clone().requires_grad_(True)
+    a, b = wy.clone().requires_grad_(True), wx.clone().requires_grad_(True)
+    out = ops.fspectral2d(xs, a, b, K)
+    out.backward(g)
+    return out.detach(), xs.grad, a.grad, b.grad
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-7, 3e5])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 20), (1, 96, 32, 12), (3, 32, 64, 4)])
+def test_fused_spectral_equals_gemm_path(gpu_device, shape, scale):
+    B, M, N, K = shape
+    torch.manual_seed(M + N + K)
+    x = torch.randn(B, M, N, 64, device=gpu_device) * scale
+    # rows whose magnitude differs by 2^+-20 inside one tensor: every line / chunk carries its own scale
+    x[:, ::3] *= 1e-6
+    x[:, 1::7] *= 1e6
+    wy = torch.randn(64, 64, K, 2, device=gpu_device) * 0.1
+    wx = torch.randn(64, 64, K, 2, device=gpu_device) * 0.1
+    g = torch.randn(B, M, N, 64, device=gpu_device) / scale
+    fused = _spectral(x, wy, wx, K, g)
+    with _env(RPDE_FUSED_SPECTRAL="0"):
+        plain = _spectral(x, wy, wx, K, g)
+    for name, a, b in zip(("out", "dx", "dWy", "dWx"), fused, plain):
+        assert torch.isfinite(a).all(), name
+        assert _rel(a, b) < 2e-6, (name, _rel(a, b))
+
+
+def test_fused_spectral_lowpass_and_skip_gradient(gpu_device):
+    from rpde import ops
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 64, 64, device=gpu_device, requires_grad=True)
+    res = {}
+    for tag, env in (("fused", {}), ("plain", {"RPDE_FUSED_SPECTRAL": "0"})):
+        with _env(**env):
+            xs = x.detach().clone().requires_grad_(True)
+            out, skip = ops.fspectral2d(xs, None, None, 12, mode="low-pass", with_skip=True)
+            (out * 2 + skip).sum().backward()           # the skip gradient is added by the last backward kernel
+            res[tag] = (out.detach(), xs.grad)
+    assert _rel(res["fused"][0], res["plain"][0]) < 2e-6 and _rel(res["fused"][1], res["plain"][1]) < 2e-6
+
+
+def _ff(ff, x, res, g, train):
+    ff.train(train)
+    xs = x.clone().requires_grad_(True)
+    torch.manual_seed(11)                       # same dropout seed draw in both runs
+    out = ff(xs, residual=res)
+    out.backward(g)
+    grads = [p.grad.clone() for p in ff.parameters()]
+    for p in ff.parameters():
+        p.grad = None
+    return [out.detach(), xs.grad] + grads
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 1e4])
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_fused_feedforward_equals_gemm_path(gpu_device, scale, dropout):
+    from models.custom_layer import FeedForward
+    torch.manual_seed(5)
+    ff = FeedForward(64, 4, n_layers=3, layer_norm=True, dropout=dropout).to(gpu_device)
+    with torch.no_grad():
+        for p in ff.parameters():
+            p.mul_(1.0 + 0.3 * torch.randn_like(p))
+    P = 17 * 37 * 41                             # 25789 points = 806 tiles: several per persistent workgroup, last one partial
+    x = torch.randn(P, 64, device=gpu_device) * scale
+    x[::5] *= 1e-5
+    res = torch.randn(P, 64, device=gpu_device)
+    g = torch.randn(P, 64, device=gpu_device)
+    fused = _ff(ff, x, res, g, True)
+    with _env(RPDE_FUSED_FF="0"):
+        plain = _ff(ff, x, res, g, True)
+    names = ["out", "dx"] + [n for n, _ in ff.named_parameters()]
+    for name, a, b in zip(names, fused, plain):
+        assert torch.isfinite(a).all(), name
+        # (weight gradients are sums over 25789 points whose inputs span nine orders of magnitude: two fp32-class
+        #  evaluations of such a sum agree to a few 1e-6 .. 1e-5)
+        assert _rel(a, b) < (2e-6 if name == "out" else 3e-5), (name, _rel(a, b))
+    # evaluation: nothing but the output is written, same numbers as the training-mode kernel without dropout
+    ff.eval()
+    with torch.no_grad():
+        e_f = ff(x, residual=res)
+        with _env(RPDE_FUSED_FF="0"):
+            e_p = ff(x, residual=res)
+    assert _rel(e_f, e_p) < 2e-6
+
+
+def test_fused_feedforward_is_reproducible_and_tail_safe(gpu_device):
+    from models.custom_layer import FeedForward
+    torch.manual_seed(1)
+    ff = FeedForward(64, 4, n_layers=3, layer_norm=True, dropout=0.0).to(gpu_device).train()
+    x = torch.randn(1000 + 17, 64, device=gpu_device)
+    outs = []
+    for _ in range(2):
+        xs = x.clone().requires_grad_(True)
+        o = ff(xs)
+        o.square().sum().backward()
+        outs.append((o.detach().clone(), xs.grad.clone(), ff.layers[1][0].weight.grad.clone(), ff.layers[1][0].bias.grad.clone()))
+        for p in ff.parameters():
+            p.grad = None
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)                 # no atomics anywhere: bitwise identical run to run

@@ -4,7 +4,8 @@ reference) through the drop-in modules -> C ABI -> HIP kernels on cuda:0.
 Tolerance (stated by BASELINE.json north_star): forward rel-L2 <= 1e-5 against
 the reference's PyTorch-CPU result (measured fp32-vs-fp64 noise floor of the
 reference itself: 1.6e-7 .. 4.0e-7).  Gradients are sums over up to 2^20 grid
-points in fp32 whose order differs from ATen's, so they get 1e-4."""
+points in fp32 whose order differs from ATen's: 2e-5 (measured <= 4.2e-6; the two
+ReLU cases carry the reference's own fp32-vs-fp64 floor, see synth.check_results)."""
 import types
 
 import pytest
@@ -18,7 +19,7 @@ from tests.golden.runner import ModuleBackend, run_case
 pytestmark = pytest.mark.gpu
 
 FWD_TOL = 1e-5
-GRAD_TOL = 1e-4
+GRAD_TOL = 2e-5
 
 
 def _namespace():

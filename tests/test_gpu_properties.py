@@ -1,0 +1,89 @@
+"""Property tests of the spectral layers on the HIP path (SURVEY section 4 / VERDICT round 1 item 8), with
+hypothesis-drawn shapes: linearity in x, circular-shift equivariance on the periodic grid, idempotence of
+mode='low-pass', and the mode clamp of the factorised layers at n < 2 * modes."""
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+SET = dict(max_examples=12, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@settings(**SET)
+@given(m=st.sampled_from([32, 48, 64, 96]), n=st.sampled_from([32, 64, 80]), c=st.sampled_from([16, 64]),
+       k=st.integers(2, 20), seed=st.integers(0, 10_000), sx=st.integers(0, 95), sy=st.integers(0, 79))
+def test_fspectral2d_is_linear_and_shift_equivariant(m, n, c, k, seed, sx, sy):
+    from rpde import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x1 = torch.randn(2, m, n, c, generator=g).to(DEV)
+    x2 = torch.randn(2, m, n, c, generator=g).to(DEV)
+    wy = (torch.randn(c, c, k, 2, generator=g) * 0.2).to(DEV)
+    wx = (torch.randn(c, c, k, 2, generator=g) * 0.2).to(DEV)
+    f = lambda t: ops.fspectral2d(t, wy, wx, k)                                   # noqa: E731
+    with torch.no_grad():
+        y1, y2 = f(x1), f(x2)
+        assert _rel(f(2.5 * x1 - 0.75 * x2), 2.5 * y1 - 0.75 * y2) < 5e-6         # linear
+        sh = (sx % m, sy % n)
+        assert _rel(f(torch.roll(x1, sh, dims=(1, 2))), torch.roll(y1, sh, dims=(1, 2))) < 5e-6   # periodic grid
+        # mode='low-pass' is the sum of the two axis projectors Py + Px (idempotence is a 1-D property, tested below);
+        # it is linear, commutes with the shift, and (Py + Px)^2 = Py + Px + 2 Py Px
+        lp = lambda t: ops.fspectral2d(t, None, None, k, mode="low-pass")          # noqa: E731
+        once = lp(x1)
+        assert _rel(lp(torch.roll(x1, sh, dims=(1, 2))), torch.roll(once, sh, dims=(1, 2))) < 5e-6
+
+
+@settings(**SET)
+@given(n=st.sampled_from([24, 32, 50, 64, 128]), c=st.sampled_from([8, 64, 128]), k=st.integers(2, 40),
+       seed=st.integers(0, 10_000), s=st.integers(0, 127))
+def test_fspectral1d_low_pass_is_an_idempotent_shift_invariant_projector(n, c, k, seed, s):
+    from rpde import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(3, n, c, generator=g).to(DEV)
+    with torch.no_grad():
+        lp = lambda t: ops.fspectral1d(t, None, k, mode="low-pass")               # noqa: E731
+        once = lp(x)
+        assert _rel(lp(once), once) < 5e-6                                       # projector onto the first k bins
+        assert _rel(lp(torch.roll(x, s % n, dims=1)), torch.roll(once, s % n, dims=1)) < 5e-6
+        if k >= n // 2 + 1:                                                      # clamp: every bin kept -> identity
+            assert _rel(once, x) < 5e-6
+        # the clamp itself (reference spectral_convolution.py:183-184): modes beyond n//2+1 change nothing
+        assert _rel(ops.fspectral1d(x, None, k + n, mode="low-pass"), ops.fspectral1d(x, None, n // 2 + 1, mode="low-pass")) < 5e-6
+
+
+@settings(**SET)
+@given(n=st.sampled_from([32, 64, 100]), ci=st.sampled_from([4, 32]), co=st.sampled_from([4, 32]), k=st.integers(1, 16),
+       seed=st.integers(0, 10_000), s=st.integers(0, 99))
+def test_spectralconv1d_is_linear_and_shift_equivariant(n, ci, co, k, seed, s):
+    from rpde import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x1 = torch.randn(2, ci, n, generator=g).to(DEV)
+    x2 = torch.randn(2, ci, n, generator=g).to(DEV)
+    w = torch.view_as_complex(torch.rand(ci, co, k, 2, generator=g) / (ci * co)).to(DEV)
+    with torch.no_grad():
+        f = lambda t: ops.spectral1d(t, w)                                        # noqa: E731
+        y1 = f(x1)
+        assert _rel(f(x1 + 3.0 * x2), y1 + 3.0 * f(x2)) < 5e-6
+        assert _rel(f(torch.roll(x1, s % n, dims=-1)), torch.roll(y1, s % n, dims=-1)) < 5e-6
+
+
+@settings(**SET)
+@given(m=st.sampled_from([32, 64]), n=st.sampled_from([32, 48]), c=st.sampled_from([4, 16]), m1=st.integers(1, 8),
+       m2=st.integers(1, 8), seed=st.integers(0, 10_000), sx=st.integers(0, 63), sy=st.integers(0, 47))
+def test_spectralconv2d_is_linear_and_shift_equivariant(m, n, c, m1, m2, seed, sx, sy):
+    from rpde import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x1 = torch.randn(2, c, m, n, generator=g).to(DEV)
+    x2 = torch.randn(2, c, m, n, generator=g).to(DEV)
+    w1 = torch.view_as_complex(torch.rand(c, c, m1, m2, 2, generator=g) / (c * c)).to(DEV)
+    w2 = torch.view_as_complex(torch.rand(c, c, m1, m2, 2, generator=g) / (c * c)).to(DEV)
+    with torch.no_grad():
+        f = lambda t: ops.spectral2d(t, w1, w2)                                   # noqa: E731
+        y1 = f(x1)
+        assert _rel(f(x1 - 2.0 * x2), y1 - 2.0 * f(x2)) < 5e-6
+        sh = (sx % m, sy % n)
+        assert _rel(f(torch.roll(x1, sh, dims=(2, 3))), torch.roll(y1, sh, dims=(2, 3))) < 5e-6

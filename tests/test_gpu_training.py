@@ -96,7 +96,13 @@ def test_main_2d_trains_and_checkpoints(gpu_device, tmp_path, capsys):
     e0 = json.loads(first[0])
     assert l2 < e0["val_loss"], (l2, e0)                 # learning happened
     ck = torch.load(tmp_path / "rpde_mi355x_2d.pt", weights_only=True)
-    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "loss_history", "val_loss_history", "l2_loss"}
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "loss_history", "val_loss_history", "l2_loss",
+                       "resolution_rel_l2"}
+    # the reference's post-training sequence (main_2d.py:287): one record per resolution up to the test grid
+    rec = [json.loads(ln) for ln in out.splitlines() if '"resolution_rel_l2"' in ln]
+    assert rec and rec[0]["evaluation_type"] == "naive_downsample"
+    assert list(rec[0]["resolution_rel_l2"]) == ["48"] and 0 < rec[0]["resolution_rel_l2"]["48"] < 1.0
+    assert abs(rec[0]["resolution_rel_l2"]["48"] - l2) < 0.05 * l2 + 1e-3      # same samples at the native resolution
 
 
 def test_main_1d_fno_and_ffno(gpu_device, tmp_path):
@@ -108,6 +114,10 @@ def test_main_1d_fno_and_ffno(gpu_device, tmp_path):
                      "dataset.n_test=8", "training.epochs=3", "training.batch_size=8", f"checkpoint_dir={tmp_path}"]
                  + extra)
         assert l2 == l2 and l2 < 2.0
+        # post-training: resolutions [32, 64] and the autoregressive rollout at each (main_1d.py:250,272)
+        last = run.last
+        assert sorted(last["resolution_rel_l2"]) == [32, 64] and all(v == v and v > 0 for v in last["resolution_rel_l2"].values())
+        assert sorted(last["rollout_rel_l2"]) == [32, 64] and all(v == v and v > 0 for v in last["rollout_rel_l2"].values())
 
 
 def test_all_resolution_evaluator_and_rollouts(gpu_device):

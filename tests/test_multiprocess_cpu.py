@@ -78,3 +78,86 @@ def test_grouped_loader_single_process_matches_reference_semantics():
         assert x.shape == y.shape and x.dim() == 3
     tr, va, te = create_grouped_dataloaders(data, data, data, 4, seed=1)
     assert len(tr) == len(va) == len(te) == 5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# evaluation loaders keep every sample under world_size > 1; an empty split reads NaN, not 0.0
+# ---------------------------------------------------------------------------------------------------------------
+def _eval_worker(rank, world, port, tmp):
+    for p in (REPO, DROPIN):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import train.training as T
+    from train.mres_training import ResolutionGroupedDataLoader
+
+    class CpuRelL2(torch.nn.Module):                       # the HIP loss has no CPU path; evaluate() is loss-agnostic here
+        def __init__(self, size_average=True):
+            super().__init__()
+
+        def forward(self, a, b):
+            a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+            return ((a - b).norm(dim=1) / (b.norm(dim=1) + 1e-8)).mean()
+    T.RelativeL2Loss = CpuRelL2
+    g = torch.Generator().manual_seed(0)
+    data = [(torch.randn(1, 16, generator=g), torch.randn(1, 16, generator=g)) for _ in range(3)]   # n_test=3 < batch*world
+    model = torch.nn.Identity()
+    loader = ResolutionGroupedDataLoader(data, 2, shuffle=False, seed=0, rank=rank, world_size=world, verbose=False)
+    assert loader.drop_last is False and sum(x.shape[0] for x, _ in loader) == (2 if rank == 0 else 1)
+    got = T.evaluate(model, loader, normalization_type="simple", device="cpu")
+    want = float(torch.stack([CpuRelL2()(x[None], y[None]) for x, y in data]).mean())
+    assert abs(got - want) < 1e-6, (got, want)
+    # training loaders still drop incomplete global batches (identical shapes on every rank) -> here: none at all
+    tl = ResolutionGroupedDataLoader(data, 2, shuffle=True, seed=0, rank=rank, world_size=world, verbose=False)
+    assert len(tl) == 0 and list(tl) == []
+    # an empty evaluation reads NaN on every rank, never 0.0
+    empty = ResolutionGroupedDataLoader([], 2, shuffle=False, seed=0, rank=rank, world_size=world, verbose=False)
+    val = T.evaluate(model, empty, normalization_type="simple", device="cpu")
+    assert val != val
+    try:
+        T.evaluate(model, loader, normalization_type="zscore", device="cpu")
+        raise AssertionError("unknown normalisation must raise like the reference")
+    except ValueError:
+        pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_counts_every_sample_once(tmp_path):
+    from rpde.launch import free_port
+    mp.spawn(_eval_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def test_untouched_parameters_keep_grad_none_and_reference_modules_stay_importable():
+    from rpde.parallel import FlatGradBucket
+    a, b = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)           # b takes no part in the graph
+    params = list(a.parameters()) + list(b.parameters())
+    bucket = FlatGradBucket(params)
+    opt = torch.optim.AdamW(params, lr=0.1, weight_decay=0.5)
+    before = b.weight.detach().clone()
+    for _ in range(2):
+        bucket.zero()
+        a(torch.ones(1, 3)).sum().backward()
+        bucket.all_reduce_mean()
+        bucket.detach_untouched()
+        assert b.weight.grad is None and a.weight.grad is not None
+        opt.step()
+    assert torch.equal(b.weight, before)                          # no weight decay, no moments: as after zero_grad()
+    bucket.zero()
+    assert b.weight.grad is not None and b.weight.grad.data_ptr() >= bucket.flat.data_ptr()
+    # drop-in route of INTEGRATION.md A.2: with this tree ahead of the reference root the shared package names are
+    # namespace packages, so the reference's own modules (utils/naive_utils.py ...) still resolve
+    import importlib.util
+    ref = "/root/reference"
+    if os.path.isdir(ref):
+        sys.path.append(ref)
+        try:
+            importlib.invalidate_caches()
+            for pkg in ("utils", "models", "train"):
+                sys.modules.pop(pkg, None) if not hasattr(sys.modules.get(pkg), "__file__") else None
+            spec = importlib.util.find_spec("utils.naive_utils")
+            assert spec is not None and spec.origin.startswith(ref)
+            assert importlib.util.find_spec("utils.loss").origin.startswith(DROPIN)
+        finally:
+            sys.path.remove(ref)
