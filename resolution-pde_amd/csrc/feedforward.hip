@@ -219,7 +219,8 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
     void* fimg = ar.take(ff3_fused_ws_floats());
     if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
     int grid = 0;
-    RPDE_TRY(ff3_fused_bwd_launch(p, ds, z_last, grad_out, dz3, buf0, buf1, grad_x, part, &grid, P, fimg, st));
+    RPDE_TRY(ff3_fused_bwd_launch(p, ds, z_last, grad_out, dz3, buf0, buf1, nullptr, part, &grid, P, fimg, st));
+    if (grad_x) RPDE_TRY(linear_dgrad_impl(buf1, p->weights[0], grad_x, P, p->dim, hid, nullptr, nullptr, st, wt));
     if (grad_weights) {
       RPDE_TRY(linear_wgrad_impl(hs[1], dz3, grad_weights[2], nullptr, P, hid, p->dim, slabs, small, st));
       RPDE_TRY(linear_wgrad_impl(hs[0], buf0, grad_weights[1], nullptr, P, hid, hid, slabs, small, st));

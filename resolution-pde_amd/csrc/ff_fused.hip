@@ -427,11 +427,14 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
 
 // ============================================================================================================
 // backward: LayerNorm / dropout / post-activation adjoint -> dz3, then the data-gradient chain
-//   du2 = (W3^T dz3) * d2,  du1 = (W2^T du2) * d1,  dx = W1^T du1
-// in the same weight-stationary, transposed form (wave w owns hidden rows 32w..32w+31 of W3^T and W2^T; W1^T lives in
-// LDS).  The kernel reads g, z3, d2, d1 and writes dz3, du2, du1 (the operands of the three weight-gradient GEMMs
-// that follow) and dx; bias, gamma and beta gradients are summed per workgroup in LDS by single-writer updates (bitwise
-// reproducible) and reduced over workgroups afterwards.
+//   du2 = (W3^T dz3) * d2,  du1 = (W2^T du2) * d1
+// in the same weight-stationary, transposed form (wave w owns hidden rows 32w..32w+31 of W3^T and W2^T).  The kernel
+// reads g, z3, d2, d1 and writes dz3, du2, du1 -- the operands of the three weight-gradient GEMMs and of
+// dx = du1 . W1, which follow as GEMMs; bias, gamma and beta gradients are summed per workgroup in LDS by
+// single-writer updates (bitwise reproducible) and reduced over workgroups afterwards.
+// d2 and d1 (half of the kernel's reads) arrive by LDS-DMA a whole tile ahead, 4 KB per wave each, no registers held:
+// with register prefetch 72 % of the wave cycles were spent waiting for them (and the dx product, whose W1^T took
+// the 64 KB of LDS the DMA areas need, moved out to a GEMM of its own).
 // ============================================================================================================
 __global__ __launch_bounds__(1024) void k_ff3_prep_bwd(const float* __restrict__ w1, const float* __restrict__ w2,
                                                        const float* __restrict__ w3, char* __restrict__ img,
@@ -499,10 +502,10 @@ struct FF3B {
 
 constexpr int FB_DZBUF = 0;                        // [2 blk][2 ks][hi|lo][1 KB]                              =  8 KB
 constexpr int FB_DUBUF = FB_DZBUF + 8192;          // [2 blk][8 kappa][hi|lo][1 KB]: du2 slices               = 32 KB
-constexpr int FB_DU1BUF = FB_DUBUF;                // du1 slices reuse the area (one extra barrier between reading du2 and writing du1)
 constexpr int FB_W3L = FB_DUBUF + 32768;           // [8 wave][4 frag][1 KB]: low pieces of the W3^T fragments  = 32 KB
-constexpr int FB_W1T = FB_W3L + 32768;             // [4 tile][8 kappa][hi|lo][1 KB]                          = 64 KB
-constexpr int FB_VEC = FB_W1T + 65536;             // gamma[64] beta[64]
+constexpr int FB_D2 = FB_W3L + 32768;              // [8 wave][4 pieces][1 KB]: d2 of the wave's slice, next tile (LDS-DMA) = 32 KB
+constexpr int FB_D1 = FB_D2 + 32768;               // the same for d1                                              = 32 KB
+constexpr int FB_VEC = FB_D1 + 32768;              // gamma[64] beta[64]
 constexpr int FB_ACC = FB_VEC + 512;               // db1[256] db2[256] db3[2][64] dgamma[2][64] dbeta[2][64] = 3584 B
 constexpr int FB_STAT1 = FB_ACC + 3584;            // [2 blk][4 tile][16 points][mean, M2]                    = 1 KB
 constexpr int FB_STAT2 = FB_STAT1 + 1024;          // [2 blk][4 tile][16 points][s1, s2, amax, -]             = 2 KB
@@ -534,13 +537,6 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       w2h[f >> 3][f & 7] = *reinterpret_cast<const f16x8*>(base + (4 + f) * 2048);
       w2l[f >> 3][f & 7] = *reinterpret_cast<const f16x8*>(base + (4 + f) * 2048 + 1024);
     }
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const uint4 hi = *reinterpret_cast<const uint4*>(base + (20 + f) * 2048);
-      const uint4 lo = *reinterpret_cast<const uint4*>(base + (20 + f) * 2048 + 1024);
-      *reinterpret_cast<uint4*>(smem + FB_W1T + (f * 8 + w) * 2048 + l * 16) = hi;
-      *reinterpret_cast<uint4*>(smem + FB_W1T + (f * 8 + w) * 2048 + 1024 + l * 16) = lo;
-    }
     float* vecw = reinterpret_cast<float*>(smem + FB_VEC);
     float* accw = reinterpret_cast<float*>(smem + FB_ACC);
     for (int i = tid; i < 128; i += 64 * FF_WAVES) vecw[i] = i < 64 ? (A.gamma ? A.gamma[i] : 1.f) : (A.beta ? A.beta[i - 64] : 0.f);
@@ -566,23 +562,33 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
     g4n = *reinterpret_cast<const float4*>(A.g + p * 64 + feat);
     z4n = *reinterpret_cast<const float4*>(A.z3 + p * 64 + feat);
   };
-  if ((int)blockIdx.x < A.ntiles) in_issue(blockIdx.x);
-  lds_barrier();                               // W1^T, vectors and zeroed accumulators are in LDS
+  // d2 / d1 of this wave's hidden slice for one tile: four 1 KB pieces (block, row tile), each lane's float4 at [piece][lane]
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  auto d_issue = [&](const float* d, int area, int tile) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float* q = d + min((long)tile * 32 + 16 * blk + li, A.P - 1) * 256 + 16 * (2 * w + t) + 4 * g;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(q), (lds_ptr)(smem + area + (w * 4 + blk * 2 + t) * 1024), 16, 0, 0);
+      }
+  };
+  if ((int)blockIdx.x < A.ntiles) {
+    in_issue(blockIdx.x);
+    d_issue(A.d2, FB_D2, blockIdx.x);
+    d_issue(A.d1, FB_D1, blockIdx.x);
+  }
+  lds_barrier();                               // vectors and zeroed accumulators are in LDS
 
+  bool first = true;
   for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
     const int next_tile = tile + gridDim.x;
+    const bool has_next = next_tile < A.ntiles;
     const long p0 = (long)tile * 32;
     const long pt3 = p0 + 16 * b3 + li;
     const bool live3 = pt3 < A.P;
     const long off3 = min(pt3, A.P - 1) * 64 + feat;
-    // d2 of this wave's hidden slice (both blocks, both tiles): needed after three barriers, fetched now
-    float4 dd[2][2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        dd[blk][t] = *reinterpret_cast<const float4*>(A.d2 + min(p0 + 16 * blk + li, A.P - 1) * 256 + 16 * (2 * w + t) + 4 * g);
-
     // ---- last-layer adjoint: dropout, LayerNorm, post-activation ----
     const float4 g4 = g4n, z4 = z4n;
     float s4[4] = {1.f, 1.f, 1.f, 1.f};
@@ -686,7 +692,6 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       if (t3 == 0 && g == 0) info[b3 * 16 + li] = dzb;
     }
     lds_barrier();                                                                    // C: dz3 fragments + bounds in LDS
-    if (next_tile < A.ntiles) in_issue(next_tile);
 
     // per point: scale of dz3 (its bound), of du2 and du1 (bounds derived from it); recomputed at each use
     auto bscales = [&](int blk, float& inv_a, float& s_du2, float& inv_b, float& s_du1, float& inv_c) {
@@ -703,7 +708,10 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
     };
 
     // ---- du2 = (W3^T dz3) * d2: this wave's 32 hidden rows ----
-    float4 d1v[2][2];
+    // the d2 pieces of this tile were requested a tile ago.  vmcnt(N) = all but the N youngest operations are done;
+    // younger than that DMA are, in program order, the next tile's g / z3 loads (2), the du1 stores (4), the d1 DMA
+    // (4) and this tile's dz3 store: 10 or 11 (first tile: only the d1 DMA and the dz3 store)
+    if (first) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
         acc = h2_mfma32(w3h[t][0], w3l0, zh0, zl0, acc);
         acc = h2_mfma32(w3h[t][1], w3l1, zh1, zl1, acc);
         const int hid = 16 * (2 * w + t) + 4 * g;
-        const float4 d = dd[blk][t];
+        const float4 d = *reinterpret_cast<const float4*>(smem + FB_D2 + (w * 4 + blk * 2 + t) * 1024 + l * 16);
         const float u[4] = {acc[0] * inv_a * d.x, acc[1] * inv_a * d.y, acc[2] * inv_a * d.z, acc[3] * inv_a * d.w};
         if (pt < A.P) {
           *reinterpret_cast<float4*>(A.du2 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
@@ -740,12 +748,11 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc_db2[16 * (2 * w + (i >> 2)) + 4 * g + (i & 3)] += bsum[i];
     }
-    // d1 of the same slice for the next layer (issued here, not earlier: registers)
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        d1v[blk][t] = *reinterpret_cast<const float4*>(A.d1 + min(p0 + 16 * blk + li, A.P - 1) * 256 + 16 * (2 * w + t) + 4 * g);
+    if (has_next) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the d2 pieces have been read: their area is free
+      d_issue(A.d2, FB_D2, next_tile);
+      in_issue(next_tile);
+    }
     lds_barrier();                                                                    // D: du2 slices in LDS
 
     // ---- du1 = (W2^T du2) * d1 ----
@@ -764,17 +771,19 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
           acc[blk][1] = h2_mfma32(w2h[1][kap], w2l[1][kap], bh, bl, acc[blk][1]);
         }
       }
-      lds_barrier();                                                                  // D': every wave has read the du2 slices
+      // the d1 pieces of this tile: younger than their DMA are the dz3 store, the four du2 stores and -- when there is
+      // a next tile -- its d2 DMA (4) and g / z3 loads (2): 11; in the last tile only the stores of live points are
+      // certain (at least two du2 stores: block 0 has a live point)
+      if (has_next) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         const long pt = p0 + 16 * blk + li;
         float q0, q1, inv_b, s_du1, q2;
         bscales(blk, q0, q1, inv_b, s_du1, q2);
-        float hv[8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int hid = 16 * (2 * w + t) + 4 * g;
-          const float4 d = d1v[blk][t];
+          const float4 d = *reinterpret_cast<const float4*>(smem + FB_D1 + (w * 4 + blk * 2 + t) * 1024 + l * 16);
           const float u[4] = {acc[blk][t][0] * inv_b * d.x, acc[blk][t][1] * inv_b * d.y,
                               acc[blk][t][2] * inv_b * d.z, acc[blk][t][3] * inv_b * d.w};
           if (pt < A.P) {
@@ -782,11 +791,12 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) bsum[4 * t + r] += u[r];
           }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) hv[4 * t + r] = u[r] * s_du1;
         }
-        ff_put_frag(smem + FB_DU1BUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
       }
+    }
+    if (has_next) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      d_issue(A.d1, FB_D1, next_tile);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsum[i] = row_sum15(bsum[i]);
@@ -794,22 +804,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc_db1[16 * (2 * w + (i >> 2)) + 4 * g + (i & 3)] += bsum[i];
     }
-    lds_barrier();                                                                    // E: du1 slices in LDS
-
-    // ---- dx = W1^T du1: feature tile t3 of point block b3 ----
-    if (A.dx) {
-      f32x4v acc3 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kap = 0; kap < 8; ++kap) {
-        const char* wb = smem + FB_W1T + (t3 * 8 + kap) * 2048 + l * 16;
-        const char* hb = smem + FB_DU1BUF + ((b3 * 8 + kap) * 2) * 1024 + l * 16;
-        acc3 = h2_mfma32(*reinterpret_cast<const f16x8*>(wb), *reinterpret_cast<const f16x8*>(wb + 1024),
-                         *reinterpret_cast<const f16x8*>(hb), *reinterpret_cast<const f16x8*>(hb + 1024), acc3);
-      }
-      float q0, q1, q2, q3, inv_c;
-      bscales(b3, q0, q1, q2, q3, inv_c);
-      if (live3) *reinterpret_cast<float4*>(A.dx + off3) = make_float4(acc3[0] * inv_c, acc3[1] * inv_c, acc3[2] * inv_c, acc3[3] * inv_c);
-    }
+    first = false;
   }
   // ---- per-workgroup sums out ----
   lds_barrier();
