@@ -69,91 +69,107 @@ def _time_gemm(desc, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def time_ff_gemm(B, device, iters=20):
-    """dominant kernel of the training step: FeedForward layer-2 forward,
-    z2 = h1 @ W2^T + b2 with the epilogue that stores h2 = gelu(dropout(z2)) and d2 = gelu'(.)*scale,
-    [P,256]x[256,256], P = B*65536.  Also times the two other heavy kernels of the layer (backward-data
-    through the stored derivative, weight gradient split over the points) for roofline_extra."""
+def _ev_time(fn, iters, warm=3):
+    """average milliseconds per call, HIP events on the current (= launch) stream"""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def time_feedforward(B, device, iters=10):
+    """the FeedForward(64 -> 256 -> 256 -> 64) of one FFNO2D layer on P = B*65536 points, through the C ABI:
+      fwd_train  rpde_feedforward_fwd with the hidden buffers given: weight preparation (one small block) + the fused
+                 kernel k_ff3_fwd_h2<true> that also stores h1, d1, h2, d2, z3 -- the DOMINANT kernel of the step
+      fwd_eval   the same call without hidden buffers (k_ff3_fwd_h2<false>: nothing but the output is written)
+      bwd_chain  rpde_feedforward_bwd with every gradient pointer NULL except nothing: preparation + k_ff3_bwd_h2
+                 (LayerNorm / dropout adjoint and the data-gradient chain; writes dz3, du2, du1)
+      wgrad      the 256 x 256 weight-gradient GEMM (split-bf16, transposing LDS reads, 192 K-slabs)
+    algorithmic bytes: every tensor that has to cross HBM once, 4 B per element"""
     from rpde import _lib
-    P, K, N = B * RES * RES, 256, 256
-    h1 = torch.randn(P, K, device=device)
-    w = torch.randn(N, K, device=device) * 0.06
-    b = torch.randn(N, device=device)
-    h2 = torch.empty(P, N, device=device)
-    d2 = torch.empty(P, N, device=device)
-    flops = 2.0 * P * K * N
+    lib = _lib.load()
+    P, dim, hid = B * RES * RES, 64, 256
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(device)          # noqa: E731
+    ws_ = [mk(hid, dim, s=0.12), mk(hid, hid, s=0.06), mk(dim, hid, s=0.06)]
+    bs_ = [mk(hid, s=0.1), mk(hid, s=0.1), mk(dim, s=0.1)]
+    gamma, beta = 1.0 + mk(dim, s=0.1), mk(dim, s=0.1)
+    x, res, gout = mk(P, dim), mk(P, dim), mk(P, dim)
+    hs = [torch.empty(P, hid, device=device) for _ in range(2)]
+    ds = [torch.empty(P, hid, device=device) for _ in range(2)]
+    z3, out = torch.empty(P, dim, device=device), torch.empty(P, dim, device=device)
+    wa, ba = _lib.ptr_array(ws_), _lib.ptr_array(bs_)
+    fp = _lib.FFParams(3, dim, 4, 1, 1e-5, 0.1, 12345, 0, C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)),
+                       gamma.data_ptr(), beta.data_ptr())
+    fp_eval = _lib.FFParams(3, dim, 4, 1, 1e-5, 0.0, 0, 0, C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)),
+                            gamma.data_ptr(), beta.data_ptr())
+    nfw = lib.rpde_feedforward_fwd_ws_bytes(dim, 4, 3)
+    wsf = _lib.workspace(nfw, device)
+    nbw = lib.rpde_feedforward_ws_bytes(P, dim, 4, 3)
+    wsb = _lib.workspace(nbw, device)
+    ha, da = _lib.ptr_array(hs), _lib.ptr_array(ds)
+    none2 = _lib.ptr_array([None, None])
+    PP = C.POINTER(C.c_void_p)
+    st = _lib.stream_ptr()
 
-    def base():
-        d = _lib.GemmDesc()
-        d.batch, d.zdiv, d.ksplit, d.alpha = 1, 1, 1, 1.0
-        return d
+    def fwd_train():
+        _lib.check(lib.rpde_feedforward_fwd(C.byref(fp), x.data_ptr(), res.data_ptr(), C.cast(ha, PP), C.cast(da, PP), z3.data_ptr(),
+                                            out.data_ptr(), P, wsf.data_ptr(), nfw, st), "ff fwd")
 
-    def presplit(wm, kmajor, n, k):
-        # what rpde_feedforward_fwd/bwd do once per call: the weight as three bf16 images
-        lib = _lib.load()
-        img = torch.empty(lib.rpde_split_weights_bytes(n, k), dtype=torch.uint8, device=device)
-        _lib.check(lib.rpde_split_weights(wm.data_ptr(), kmajor, wm.shape[1], n, k, img.data_ptr(), _lib.stream_ptr()),
-                   "split_weights")
-        return img
+    def fwd_eval():
+        _lib.check(lib.rpde_feedforward_fwd(C.byref(fp_eval), x.data_ptr(), res.data_ptr(), C.cast(none2, PP), C.cast(none2, PP),
+                                            z3.data_ptr(), out.data_ptr(), P, wsf.data_ptr(), nfw, st), "ff fwd eval")
 
-    d = base()                                           # forward
-    d.A, d.B, d.C = h1.data_ptr(), w.data_ptr(), h2.data_ptr()
-    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = P, N, K, 1, 1
-    d.lda, d.ldb, d.ldc = K, K, N
-    d.bias, d.bias_mode, d.write_act, d.aux_out = b.data_ptr(), 1, 1, d2.data_ptr()
-    d.drop_p, d.drop_seed, d.drop_ld, d.drop_where = 0.1, 12345, N, 4
-    wimg = presplit(w, 1, N, K)
-    d.b_split = wimg.data_ptr()
-    ms = _time_gemm(d, iters)
-    extra = []
-    e = base()                                           # backward-data: gx = (g @ W) * d + per-tile column sums
-    cs = torch.empty(((P + 127) // 128) * K, device=device)
-    wtimg = presplit(w, 0, K, N)                         # W [out,in] is x-major for this product
-    e.A, e.B, e.C = h2.data_ptr(), w.data_ptr(), h1.data_ptr()
-    e.M, e.N, e.K, e.a_kmajor, e.b_kmajor = P, K, N, 1, 0
-    e.lda, e.ldb, e.ldc = N, K, K
-    e.b_split = wtimg.data_ptr()
-    e.epi_dact, e.aux, e.ldaux, e.colsum = 100, d2.data_ptr(), K, cs.data_ptr()
-    t = _time_gemm(e, max(5, iters // 2))
-    byt = 4.0 * P * (N + 2 * K)                          # read g, read d, write gx
-    extra.append({"kernel": "gemm split-bf16 NT backward-data [P,256]x[256,256] * stored derivative + bias column sums",
-                  "bound": "hbm", "achieved": round(byt / (t * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                  "frac": round(byt / (t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "ms_per_launch": round(t, 4),
-                  "fp32_equiv_tflops": round(flops / (t * 1e-3) / 1e12, 2)})
-    f = base()                                           # weight gradient: W' = g^T @ h, split over the points
-    S = 192                                              # = rpde_feedforward_bwd: 768 workgroups / 4 tiles
-    slabs = torch.empty(S * N * K, device=device)
-    f.A, f.B, f.C = h2.data_ptr(), h1.data_ptr(), slabs.data_ptr()
-    f.M, f.N, f.K, f.a_kmajor, f.b_kmajor = N, K, P, 0, 0
-    f.lda, f.ldb, f.ldc, f.ksplit, f.sCk = N, K, K, S, N * K
-    t = _time_gemm(f, max(5, iters // 2))
-    # 69 flop/B (reads g and h once) is above the split path's ridge (417 TF / 8 TB/s = 52): matrix bound
-    extra.append({"kernel": "gemm split-bf16 TN weight gradient [256,P]x[P,256] (transposing LDS reads), split-K 192 slabs",
-                  "bound": "mfma", "achieved": round(flops / (t * 1e-3) / 1e12, 2), "peak": round(PEAK_BF16_MFMA_TF / 6, 1),
-                  "unit": "TFLOP/s (fp32-equivalent: 6 bf16 MFMA flops per fp32 flop)",
-                  "frac": round(flops / (t * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TF / 6), 4), "ms_per_launch": round(t, 4),
-                  "hbm_gbs": round(8.0 * P * N / (t * 1e-3) / 1e9, 1)})
-    alg_bytes = 4.0 * P * (K + 2 * N) + 4.0 * N * K         # read h1, write h2 and d2, read W2
-    return ms, flops / (ms * 1e-3) / 1e12, flops, extra, alg_bytes
+    def bwd_chain():
+        _lib.check(lib.rpde_feedforward_bwd(C.byref(fp), x.data_ptr(), C.cast(ha, PP), C.cast(da, PP), z3.data_ptr(), gout.data_ptr(),
+                                            None, None, None, None, None, P, wsb.data_ptr(), nbw, st), "ff bwd")
+
+    assert lib.rpde_feedforward_is_fused(dim, 4, 3, P) == 1, "the fused FeedForward kernel does not cover the headline shape"
+    t_ft = _ev_time(fwd_train, iters)
+    t_fe = _ev_time(fwd_eval, iters)
+    t_bc = _ev_time(bwd_chain, iters)
+    # the 256 x 256 weight gradient, as rpde_feedforward_bwd launches it
+    d = _lib.GemmDesc()
+    d.batch, d.zdiv, d.alpha = 1, 1, 1.0
+    S = 192
+    slabs = torch.empty(S * hid * hid, device=device)
+    d.A, d.B, d.C = ds[1].data_ptr(), hs[0].data_ptr(), slabs.data_ptr()
+    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = hid, hid, P, 0, 0
+    d.lda, d.ldb, d.ldc, d.ksplit, d.sCk = hid, hid, hid, S, hid * hid
+    t_wg = _time_gemm(d, max(5, iters // 2))
+    flops_fwd = 2.0 * P * (dim * hid + hid * hid + hid * dim)
+    by_train = 4.0 * P * (4 * dim + 4 * hid)            # x, residual, out, z3 + h1, d1, h2, d2
+    by_eval = 4.0 * P * 3 * dim                         # x, residual, out
+    by_chain = 4.0 * P * (3 * dim + 4 * hid)            # g, z3, dz3 + d2, d1, du2, du1
+    return {"fwd_train_ms": t_ft, "fwd_eval_ms": t_fe, "bwd_chain_ms": t_bc, "wgrad_ms": t_wg, "flops_fwd": flops_fwd,
+            "bytes_train": by_train, "bytes_eval": by_eval, "bytes_chain": by_chain, "flops_wgrad": 2.0 * P * hid * hid,
+            "bytes_wgrad": 8.0 * P * hid}
 
 
 def time_spectral(B, device, iters=10):
+    """FSpectralConv2d.forward_fourier and its backward at [B,256,256,64], 20 modes (fused h2 path)"""
     from rpde import ops
     x = torch.randn(B, RES, RES, 64, device=device)
     wy = torch.randn(64, 64, 20, 2, device=device) * 0.1
     wx = torch.randn(64, 64, 20, 2, device=device) * 0.1
     with torch.no_grad():
-        for _ in range(2):
-            ops.fspectral2d(x, wy, wx, 20)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.fspectral2d(x, wy, wx, 20)
-        e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+        ms = _ev_time(lambda: ops.fspectral2d(x, wy, wx, 20), iters, warm=2)
+    xg = x.clone().requires_grad_(True)
+    wyg, wxg = wy.clone().requires_grad_(True), wx.clone().requires_grad_(True)
+    gg = torch.randn_like(x)
+
+    def fb():
+        ops.fspectral2d(xg, wyg, wxg, 20).backward(gg)
+        xg.grad = None
+
+    ms_fb = _ev_time(fb, iters, warm=2)
     alg_bytes = 4.0 * B * RES * RES * 2 * 64 + 2 * 8.0 * 64 * 64 * 20
-    return ms, alg_bytes / (ms * 1e-3) / 1e9, alg_bytes
+    return ms, alg_bytes / (ms * 1e-3) / 1e9, alg_bytes, ms_fb - ms
 
 
 def host_cores() -> int:
@@ -328,19 +344,30 @@ def main():
     elif rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        g_ms, g_tf, g_flops, g_extra, g_bytes = time_ff_gemm(B, device)
-        log(f"FF GEMM {g_ms:.3f} ms = {g_tf:.1f} TF")
-        s_ms, s_gbs, s_bytes = time_spectral(B, device)
-        log(f"spectral fwd {s_ms:.3f} ms = {s_gbs:.0f} GB/s algorithmic")
-        traffic = step_traffic = None
+        ff = time_feedforward(B, device)
+        log(f"FeedForward: fwd(train) {ff['fwd_train_ms']:.3f} ms, fwd(eval) {ff['fwd_eval_ms']:.3f} ms, "
+            f"bwd chain {ff['bwd_chain_ms']:.3f} ms, wgrad {ff['wgrad_ms']:.3f} ms")
+        s_ms, s_gbs, s_bytes, s_bwd_ms = time_spectral(B, device)
+        log(f"spectral fwd {s_ms:.3f} ms = {s_gbs:.0f} GB/s algorithmic; bwd {s_bwd_ms:.3f} ms")
+        traffic = step_traffic = traffic_src = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 blob = json.load(open(tpath))
-                traffic = blob.get("ff_gemm_256x256", {}).get(f"B{B}")
+                traffic = blob.get("dominant_kernel", {}).get(f"B{B}")
                 step_traffic = blob.get("train_step", {}).get(f"B{B}", {}).get("hbm_bytes_per_step")
+                traffic_src = blob.get("source")
             except Exception:
                 traffic = step_traffic = None
+
+        def hbm(kernel, byt, ms, **extra):
+            gbs = byt / (ms * 1e-3) / 1e9
+            d = {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                 "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": byt, "ms_per_launch": round(ms, 4)}
+            d.update(extra)
+            return d
+
+        tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 2)                                  # noqa: E731
         line = {
             "metric": "training samples/sec, FFNO2D NS 256^2", "value": round(value, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -354,28 +381,43 @@ def main():
                        "step_ms_p10_p50_p90": [round(pct(0.1), 3), round(pct(0.5), 3), round(pct(0.9), 3)],
                        "train_rel_l2_first_last": [round(lh[0], 6), round(lh[-1], 6)],
                        "target": "input advanced by a fixed spectral filter (utils/synthetic.py:advance)"},
-            # fp32 in/out/accumulate; products on the bf16 matrix pipe by exact 3-way splitting (6 MFMA terms):
-            # compute roof 2500/6 = 417 TF(fp32-equivalent), arithmetic intensity 43 flop/B < ridge 52 -> HBM bound
-            "roofline": {"kernel": "gemm split-bf16 NT [P,256]x[256,256]+bias -> h=gelu(dropout(z)), d=gelu'*scale "
-                                   "(FeedForward layer 2 forward)",
-                         "bound": "hbm", "achieved": round(g_bytes / (g_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-                         "unit": "GB/s", "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": g_bytes, "flops_per_launch": g_flops,
-                         "ms_per_launch": round(g_ms, 4), "fp32_equiv_tflops": round(g_tf, 2),
-                         "frac_of_fp32_mfma_peak": round(g_tf / PEAK_F32_MFMA_TF, 4),
-                         "frac_of_split_bf16_compute_roof": round(g_tf / (PEAK_BF16_MFMA_TF / 6), 4)},
-            "roofline_extra": g_extra,
-            "roofline_spectral": {"kernel": "FSpectralConv2d.forward_fourier (6 GEMM launches + weight pack)",
-                                  "bound": "hbm", "achieved": round(s_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": round(s_gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes": s_bytes,
-                                  "ms_per_call": round(s_ms, 4)},
+            # fp32 in / out / accumulate everywhere.  Products run on the f16 matrix pipe by two-piece splitting with
+            # dynamic power-of-two scaling (3 MFMA terms, csrc/h2.h) in the fused kernels and on the bf16 pipe by
+            # three-piece splitting (6 terms) in the remaining GEMMs.
+            "roofline": hbm("k_ff3_fwd_h2<train>: fused FeedForward 64->256->256->64 forward of one layer (+ weight preparation, "
+                            "1 block): reads x, residual; writes out, z3 and the saved h1, d1, h2, d2",
+                            ff["bytes_train"], ff["fwd_train_ms"], traffic=traffic, traffic_source=traffic_src,
+                            flops_per_launch=ff["flops_fwd"], fp32_equiv_tflops=tf(ff["flops_fwd"], ff["fwd_train_ms"]),
+                            frac_of_h2_matrix_roof=round(tf(ff["flops_fwd"], ff["fwd_train_ms"]) / (PEAK_BF16_MFMA_TF / 3), 4),
+                            note="hidden activations never leave the CU; the kernel is bound by the vector work of "
+                                 "bias + dropout + GELU + GELU' (SQ counters in profiles/), not by HBM or the matrix pipe"),
+            "roofline_extra": [
+                hbm("k_ff3_fwd_h2<eval>: the same forward in evaluation (writes nothing but the output)", ff["bytes_eval"],
+                    ff["fwd_eval_ms"], fp32_equiv_tflops=tf(ff["flops_fwd"], ff["fwd_eval_ms"])),
+                hbm("k_ff3_bwd_h2: LayerNorm/dropout adjoint + data-gradient chain (reads g, z3, d2, d1; writes dz3, du2, du1)",
+                    ff["bytes_chain"], ff["bwd_chain_ms"]),
+                {"kernel": "gemm split-bf16 TN weight gradient [256,P]x[P,256] (transposing LDS reads), split-K 192 slabs",
+                 "bound": "mfma", "achieved": tf(ff["flops_wgrad"], ff["wgrad_ms"]), "peak": round(PEAK_BF16_MFMA_TF / 6, 1),
+                 "unit": "TFLOP/s (fp32-equivalent: 6 bf16 MFMA flops per fp32 flop)",
+                 "frac": round(tf(ff["flops_wgrad"], ff["wgrad_ms"]) / (PEAK_BF16_MFMA_TF / 6), 4),
+                 "ms_per_launch": round(ff["wgrad_ms"], 4),
+                 "hbm_gbs": round(ff["bytes_wgrad"] / (ff["wgrad_ms"] * 1e-3) / 1e9, 1)},
+                hbm("FSpectralConv2d backward (adjoint analysis, mode mix^T + weight gradients, adjoint synthesis + skip)",
+                    2 * s_bytes, s_bwd_ms),
+            ],
+            "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_dft_analysis_h2 (both axes, one launch) + mode mix "
+                                     "(2 GEMM) + k_spec_split_h2 (2) + k_dft_synthesis2_h2 (field written once)",
+                                     s_bytes, s_ms, note="x is read twice (once per axis; partial sums of the other axis "
+                                     "would be larger than the field), so 1.5x the algorithmic bytes is the floor of this "
+                                     "formulation: frac <= 0.52 at the 6.3 TB/s this box streams"),
         }
         if step_traffic:
             # whole training step against the HBM roof: PMC-measured bytes of one step / this run's step time
             gbs = step_traffic / (ms_step * 1e-3) / 1e9
-            line["roofline_step"] = {"bound": "hbm", "traffic_bytes_per_step": step_traffic, "achieved": round(gbs, 1),
-                                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                     "note": "all kernels of one step; this box sustains 6.3 TB/s on a pure fill"}
+            line["roofline_step"] = {"bound": "hbm", "traffic_bytes_per_step": step_traffic, "traffic_source": traffic_src,
+                                     "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                     "note": "all kernels of one step; PMC bytes from the committed profile, time from this run"}
         if world == 1:
             line["parity"] = {"fwd_rel_l2_vs_cpu_oracle": parity_check(device), "tolerance": 1e-5}
             log(f"parity {line['parity']}")

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Fold the two PMC passes into profiles/traffic.json.
-HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB and on gfx950
-FETCH_SIZE reports exactly half of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM)."""
+"""Fold the PMC passes into profiles/traffic.json.
+    python profiles/parse_pmc.py <kernels FETCH dir> <kernels WRITE dir> <step FETCH dir> <step WRITE dir> <B> <steps in the step run> <out.json> <source tag>
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB and on gfx950 FETCH_SIZE reports
+exactly half of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM); Infinity-Cache hits are counted
+as fetches."""
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
@@ -15,12 +18,13 @@ def per_kernel(path, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void rpde::", "").replace("rpde::", "")
+            acc.setdefault(name, []).append(float(r["Counter_Value"]))
     return acc
 
 
-def main(fetch_dir, write_dir, B, out):
-    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+def main(kf, kw, sf, sw, B, steps, out, source):
+    fe, wr = per_kernel(kf, "FETCH_SIZE"), per_kernel(kw, "WRITE_SIZE")
     res = {}
     for name in fe:
         if name not in wr:
@@ -29,17 +33,23 @@ def main(fetch_dir, write_dir, B, out):
         w = sorted(wr[name])[len(wr[name]) // 2]
         res[name] = {"launches": len(fe[name]), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                      "hbm_bytes_per_launch": (2 * f + w) * 1024}
-    # dominant kernel = split-bf16 NT 128x128 (its epilogue writes h and d); pmc_target.py launches that
-    # instantiation for the forward and for the backward-data GEMM: take the larger (forward, 3 P*256 floats)
-    dom = [k for k in res if "gemm_bf16x3_kernel<2, 2, 2, 2, true, true" in k]
-    blob = json.load(open(out)) if os.path.exists(out) else {}
+    blob = {"source": source,
+            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2 FETCH + WRITE) KiB "
+                   "(gfx950: FETCH_SIZE counts half of wide streaming reads); median over the launches of a kernel"}
+    dom = [k for k in res if k.startswith("k_ff3_fwd_h2<true>")]
     if dom:
-        blob.setdefault("ff_gemm_256x256", {})[f"B{B}"] = max(res[k]["hbm_bytes_per_launch"] for k in dom)
-    blob.setdefault("per_kernel", {})[f"B{B}"] = res
+        blob["dominant_kernel"] = {f"B{B}": res[dom[0]]["hbm_bytes_per_launch"], "kernel": dom[0]}
+    blob["per_kernel"] = {f"B{B}": res}
+    sfe, swr = per_kernel(sf, "FETCH_SIZE"), per_kernel(sw, "WRITE_SIZE")
+    rd = sum(sum(v) for v in sfe.values()) * 2 * 1024 / steps
+    wb = sum(sum(v) for v in swr.values()) * 1024 / steps
+    blob["train_step"] = {f"B{B}": {"read_bytes": rd, "write_bytes": wb, "hbm_bytes_per_step": rd + wb,
+                                   "how": f"all kernels of `bench.py --steps-only` summed / {steps} steps"}}
     json.dump(blob, open(out, "w"), indent=1)
-    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
-        print(f"{k[:90]:90s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch  (x{v['launches']})")
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:14]:
+        print(f"{k[:84]:84s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch  (x{v['launches']})")
+    print(f"train step: {(rd + wb) / 1e9:.1f} GB  (read {rd / 1e9:.1f}, written {wb / 1e9:.1f})")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7], sys.argv[8])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Runs only the dominant kernel (FeedForward 256->256 GEMM with staged GELU+dropout, B*65536 points)
-and the spectral forward a few times: the target of the separate rocprofv3 --pmc passes
-(FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950, MI355X_MICROARCH.md 'PMC slots')."""
+"""Target of the separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950,
+MI355X_MICROARCH.md 'PMC slots'): the fused FeedForward kernels, the weight-gradient GEMM and the spectral
+forward / backward a few times each, at B*65536 points."""
 import os
 import sys
 
@@ -11,8 +11,8 @@ sys.path.insert(0, os.path.join(REPO, "resolution-pde_amd"))
 import torch  # noqa: E402
 import bench  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-print("ff gemm", bench.time_ff_gemm(B, dev, iters=3))
+print("feedforward", bench.time_feedforward(B, dev, iters=3))
 print("spectral", bench.time_spectral(B, dev, iters=2))
