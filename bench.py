@@ -172,6 +172,26 @@ def time_spectral(B, device, iters=10):
     return ms, alg_bytes / (ms * 1e-3) / 1e9, alg_bytes, ms_fb - ms
 
 
+def time_cfg5(device, B=8, iters=10):
+    """BASELINE config 5: SpectralConv2d(32,32,12,12) forward at [B,32,512,512] against SURVEY 8(d)'s
+    67.11 MB*B + 2.36 MB per layer, and the whole FNO2d(1,1,12,12,32) evaluation forward / rollout step"""
+    from models.fno import FNO2d
+    from rpde import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(B, 32, 512, 512, generator=g).to(device)
+    w1 = (torch.rand(32, 32, 12, 12, 2, generator=g) / 1024).to(device)
+    w2 = (torch.rand(32, 32, 12, 12, 2, generator=g) / 1024).to(device)
+    w1, w2 = torch.view_as_complex(w1), torch.view_as_complex(w2)
+    with torch.no_grad():
+        ms = _ev_time(lambda: ops.spectral2d(x, w1, w2), iters)
+        del x
+        torch.manual_seed(0)
+        model = FNO2d(1, 1, modes1=12, modes2=12, width=32).to(device).eval()
+        u = torch.randn(B, 1, 512, 512, generator=g).to(device)
+        ms_model = _ev_time(lambda: model(u), iters)
+    return ms, 67.11e6 * B + 2.36e6, ms_model
+
+
 def host_cores() -> int:
     """cores this process may really use: affinity mask, capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -349,6 +369,8 @@ def main():
             f"bwd chain {ff['bwd_chain_ms']:.3f} ms, wgrad {ff['wgrad_ms']:.3f} ms")
         s_ms, s_gbs, s_bytes, s_bwd_ms = time_spectral(B, device)
         log(f"spectral fwd {s_ms:.3f} ms = {s_gbs:.0f} GB/s algorithmic; bwd {s_bwd_ms:.3f} ms")
+        c5_ms, c5_bytes, c5_model_ms = time_cfg5(device)
+        log(f"config 5: SpectralConv2d 512^2 forward {c5_ms:.3f} ms, FNO2d eval forward {c5_model_ms:.3f} ms (B=8)")
         traffic = step_traffic = traffic_src = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -404,6 +426,10 @@ def main():
                  "hbm_gbs": round(ff["bytes_wgrad"] / (ff["wgrad_ms"] * 1e-3) / 1e9, 1)},
                 hbm("FSpectralConv2d backward (adjoint analysis, mode mix^T + weight gradients, adjoint synthesis + skip)",
                     2 * s_bytes, s_bwd_ms),
+                hbm("BASELINE config 5: SpectralConv2d(32,32,12,12) forward at [8,32,512,512] (k_cf_analysis_h2, row DFT, "
+                    "mode mix, row DFT, k_cf_synthesis_h2), SURVEY 8(d): 67.11 MB*B + 2.36 MB", c5_bytes, c5_ms,
+                    fno2d_512_eval_forward_ms_B8=round(c5_model_ms, 3),
+                    fno2d_512_eval_samples_per_s=round(8 / c5_model_ms * 1e3, 1)),
             ],
             "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_dft_analysis_h2 (both axes, one launch) + mode mix "
                                      "(2 GEMM) + k_spec_split_h2 (2) + k_dft_synthesis2_h2 (field written once)",

@@ -228,6 +228,10 @@ int rpde_linear_bwd(const float* x, const float* w, const float* grad_out,
 size_t rpde_conv1x1_ws_bytes(int B, int Cin, int Cout, int64_t S);
 int rpde_conv1x1_fwd(const float* x, const float* w, const float* b, float* out,
                      int B, int Cin, int Cout, int64_t S, int act_in, int accumulate, void* stream);
+/* the same with an activation applied to the result before it is stored (evaluation-mode FNO blocks:
+ * out = act(spectral + W . x + b) written once, models/fno_blocks.py:25-45 of the reference) */
+int rpde_conv1x1_act_fwd(const float* x, const float* w, const float* b, float* out,
+                         int B, int Cin, int Cout, int64_t S, int act_in, int accumulate, int act_out, void* stream);
 int rpde_conv1x1_bwd(const float* x, const float* w, const float* grad_out,
                      float* grad_x, float* grad_w, float* grad_b,
                      int B, int Cin, int Cout, int64_t S, int act_in, int accumulate_gx,

@@ -3,6 +3,7 @@
 #include "rpde_internal.h"
 #include "plan.h"
 #include "fused_spectral.h"
+#include "cf_dft.h"
 
 #include <stdarg.h>
 #include <map>
@@ -141,6 +142,7 @@ static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, i
       RPDE_TRY(split_weights(p->fa, 0, p->ldn, n, m2, p->img[IMG_FAT], st));
       if (n % 32 == 0 && n <= 256 && m2 <= 48) RPDE_TRY(h2_build_tables(p, st));
     }
+    if (planar && p->ldn == n && cf_h2_eligible(n, 2 * p->kp)) RPDE_TRY(cf_build_tables(p, st));
   } else {
     if (bot < 0) bot = modes;
     RPDE_CHECK_ARG(modes <= n && bot <= n && modes >= 0 && bot >= 0 && modes + bot >= 1, "plan: rows (%d,%d) vs M %d", modes, bot, n);
@@ -202,6 +204,8 @@ int rpde_plan_destroy(rpde_plan* p) {
   for (int i = 0; i < 2; ++i) {
     if (p->h2_ana[i]) (void)hipFree(p->h2_ana[i]);
     if (p->h2_syn[i]) (void)hipFree(p->h2_syn[i]);
+    if (p->cf_ana[i]) (void)hipFree(p->cf_ana[i]);
+    if (p->cf_syn[i]) (void)hipFree(p->cf_syn[i]);
   }
   delete p;
   return RPDE_OK;

@@ -299,8 +299,14 @@ size_t rpde_conv1x1_ws_bytes(int B, int Cin, int Cout, int64_t S) {
 
 int rpde_conv1x1_fwd(const float* x, const float* w, const float* b, float* out, int B, int Cin, int Cout, int64_t S,
                      int act_in, int accumulate, void* stream) {
+  return rpde_conv1x1_act_fwd(x, w, b, out, B, Cin, Cout, S, act_in, accumulate, RPDE_ACT_IDENTITY, stream);
+}
+
+int rpde_conv1x1_act_fwd(const float* x, const float* w, const float* b, float* out, int B, int Cin, int Cout, int64_t S,
+                         int act_in, int accumulate, int act_out, void* stream) {
   RPDE_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && S > 0 && S < (1L << 31), "conv1x1_fwd: bad arguments");
   rpde_gemm_desc d = gemm_desc();
+  d.write_act = act_out;
   d.A = w; d.a_kmajor = 1; d.lda = Cin;
   d.B = x; d.b_kmajor = 0; d.ldb = S;
   d.C = out; d.ldc = S;

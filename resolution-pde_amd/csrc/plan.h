@@ -18,6 +18,9 @@ struct rpde_plan {
   // fragments for the fused kernels (fused_spectral.hip): [0] forward operand (Fa / Fs), [1] adjoint (Fs^T / Fa^T)
   void* h2_ana[2];
   void* h2_syn[2];
+  // real, planar plans (channels-first layers, resizers) that cf_dft.hip covers: the tables as B fragments
+  void* cf_ana[2];
+  void* cf_syn[2];
 };
 
 namespace rpde {

@@ -15,6 +15,7 @@
 #include "rpde_internal.h"
 #include "plan.h"
 #include "pointwise.h"
+#include "cf_dft.h"
 
 namespace rpde {
 
@@ -112,6 +113,7 @@ static int launch_mix(int which, const float* a, const float* b, const float* w1
 
 // rows x n  ->  rows x 2kp   (forward real DFT along the contiguous axis), optional act on the input
 static int cf_analysis(const rpde_plan* pl, const float* x, float* spec, long rows, int n, int act_in, hipStream_t st) {
+  if (!act_in && pl->cf_ana[0] && rows >= 16 && cf_h2_eligible(n, 2 * pl->kp)) return cf_analysis_h2(pl, 0, x, spec, rows, 1.f, st);
   rpde_gemm_desc d = gemm_desc();
   d.A = x; d.a_kmajor = 1; d.lda = n; d.act_a = act_in;
   d.B = pl->fa; d.b_kmajor = 1; d.ldb = pl->ldn;
@@ -122,6 +124,7 @@ static int cf_analysis(const rpde_plan* pl, const float* x, float* spec, long ro
 // rows x 2kp -> rows x n  (C2R synthesis)
 static int cf_synthesis(const rpde_plan* pl, const float* spec, float* out, long rows, int n, hipStream_t st,
                         float alpha = 1.f) {
+  if (pl->cf_syn[0] && rows >= 16 && cf_h2_eligible(n, 2 * pl->kp)) return cf_synthesis_h2(pl, 0, spec, out, rows, alpha, st);
   rpde_gemm_desc d = gemm_desc();
   d.alpha = alpha;
   d.A = spec; d.a_kmajor = 1; d.lda = 2L * pl->kp;
@@ -132,6 +135,7 @@ static int cf_synthesis(const rpde_plan* pl, const float* spec, float* out, long
 }
 // adjoint of synthesis: g[rows,n] . Fs -> [rows, 2kp]
 static int cf_synthesis_T(const rpde_plan* pl, const float* g, float* gspec, long rows, int n, hipStream_t st) {
+  if (pl->cf_ana[1] && rows >= 16 && cf_h2_eligible(n, 2 * pl->kp)) return cf_analysis_h2(pl, 1, g, gspec, rows, 1.f, st);
   rpde_gemm_desc d = gemm_desc();
   d.A = g; d.a_kmajor = 1; d.lda = n;
   d.B = pl->fs; d.b_kmajor = 0; d.ldb = 2L * pl->kp;
@@ -142,6 +146,7 @@ static int cf_synthesis_T(const rpde_plan* pl, const float* g, float* gspec, lon
 // adjoint of analysis: dspec[rows,2kp] . Fa -> gx[rows,n], through act'(x) when act_in
 static int cf_analysis_T(const rpde_plan* pl, const float* dspec, float* gx, long rows, int n, int act_in, const float* x,
                          hipStream_t st) {
+  if (!act_in && pl->cf_syn[1] && rows >= 16 && cf_h2_eligible(n, 2 * pl->kp)) return cf_synthesis_h2(pl, 1, dspec, gx, rows, 1.f, st);
   rpde_gemm_desc d = gemm_desc();
   d.A = dspec; d.a_kmajor = 1; d.lda = 2L * pl->kp;
   d.B = pl->fa; d.b_kmajor = 0; d.ldb = pl->ldn;

@@ -22,6 +22,10 @@ def _coord(c, device):
 class _FNO(nn.Module):
     def _run(self, lifted):
         h = ops.conv1x1(lifted, self.lifting.weight, self.lifting.bias)
+        if not torch.is_grad_enabled():      # evaluation / rollout: every block writes its activated output once
+            for blk in self.fno_blocks:
+                h = blk.activated(h)
+            return self.projection(h, "identity")
         act_in = "identity"
         for blk in self.fno_blocks:          # h holds the pre-activation of the previous block
             h = blk.pre_activation(h, act_in)

@@ -29,7 +29,17 @@ class _FNOBlock(nn.Module):
         spec = self.spectral_conv(x, act_in)
         return ops.conv1x1(x, self.bypass_conv.weight, self.bypass_conv.bias, act_in, acc=spec, acc_owned=True)
 
+    def activated(self, x):
+        """evaluation only: activation(spectral_conv(x) + bypass_conv(x)) with the activation applied by the
+        kernel that writes the block's output (stored once, already activated, so that the next block's truncated
+        DFT streams it without evaluating the activation again)"""
+        spec = self.spectral_conv(x, "identity")
+        return ops.conv1x1_act_eval(x, self.bypass_conv.weight, self.bypass_conv.bias, spec, act_name(self.activation))
+
     def forward(self, x):
+        import torch
+        if not torch.is_grad_enabled():
+            return self.activated(x)
         return ops.activation(self.pre_activation(x), act_name(self.activation))
 
 

@@ -400,6 +400,21 @@ def conv1x1(x, w, b=None, act_in: str = "identity", acc=None, acc_owned: bool = 
     return _Conv1x1.apply(x, w, b, ACT[act_in], acc, acc_owned)
 
 
+def conv1x1_act_eval(x, w, b, acc, act_out: str):
+    """evaluation only (no autograd): acc <- act_out(acc + W . x + b), in place in the temporary `acc`"""
+    lib = load()
+    x = _f32c(x)
+    B, Ci = x.shape[0], x.shape[1]
+    S = x[0, 0].numel()
+    Co = w.shape[0]
+    w2 = _f32c(w.detach()).reshape(Co, Ci)
+    bb = _f32c(b.detach()) if b is not None else None
+    out = acc if (acc.dtype == torch.float32 and acc.is_contiguous()) else _f32c(acc).clone()
+    check(lib.rpde_conv1x1_act_fwd(ptr(x), ptr(w2), ptr(bb), ptr(out), B, Ci, Co, S, 0, 1, ACT[act_out], stream_ptr()),
+          "conv1x1_act_fwd")
+    return out
+
+
 class _Act(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act: int):

@@ -132,3 +132,59 @@ def test_fused_feedforward_is_reproducible_and_tail_safe(gpu_device):
             p.grad = None
     for a, b in zip(*outs):
         assert torch.equal(a, b)                 # no atomics anywhere: bitwise identical run to run
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 1e5])
+def test_channels_first_h2_dft_equals_gemm_path(gpu_device, scale):
+    """cf_dft.hip (SpectralConv1d/2d stage along the contiguous axis, spectral resize) against the GEMM path"""
+    from rpde import ops
+    torch.manual_seed(9)
+    x2 = torch.randn(2, 8, 64, 256, device=gpu_device) * scale
+    x2[:, ::3] *= 1e-4
+    w1 = (torch.rand(8, 8, 6, 12, dtype=torch.cfloat) / 64).to(gpu_device)
+    w2 = (torch.rand(8, 8, 6, 12, dtype=torch.cfloat) / 64).to(gpu_device)
+    x1 = torch.randn(3, 8, 1024, device=gpu_device) * scale
+    w = (torch.rand(8, 8, 16, dtype=torch.cfloat) / 64).to(gpu_device)
+    g2 = torch.randn(2, 8, 64, 256, device=gpu_device) / scale
+    g1 = torch.randn(3, 8, 1024, device=gpu_device) / scale
+
+    def run():
+        a = x2.clone().requires_grad_(True)
+        p, q = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        o2 = ops.spectral2d(a, p, q)
+        o2.backward(g2)
+        b = x1.clone().requires_grad_(True)
+        r = w.clone().requires_grad_(True)
+        o1 = ops.spectral1d(b, r)
+        o1.backward(g1)
+        with torch.no_grad():
+            rz = ops.resize2d(x2, (128, 128))
+            rz1 = ops.resize1d(x1, 384)
+        return [o2.detach(), a.grad, torch.view_as_real(p.grad), torch.view_as_real(q.grad), o1.detach(), b.grad,
+                torch.view_as_real(r.grad), rz, rz1]
+
+    fused = run()
+    with _env(RPDE_FUSED_CF="0"):
+        plain = run()
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert torch.isfinite(a).all(), i
+        assert _rel(a, b) < 3e-6, (i, _rel(a, b))
+
+
+def test_fno2d_evaluation_path_equals_training_path_forward(gpu_device):
+    """without autograd every FNO block stores its activated output once (conv1x1 with a fused output activation);
+    with autograd the blocks pass pre-activations: same numbers"""
+    from models.fno import FNO1d, FNO2d
+    torch.manual_seed(2)
+    m2 = FNO2d(1, 1, modes1=6, modes2=6, width=16).to(gpu_device)
+    x = torch.randn(2, 1, 128, 128, device=gpu_device)
+    with torch.no_grad():
+        e = m2(x)
+        be = m2.fno_blocks[0](torch.randn(2, 16, 128, 128, device=gpu_device))
+    t = m2(x.requires_grad_(True))
+    assert _rel(e, t.detach()) < 2e-6 and torch.isfinite(be).all()
+    m1 = FNO1d(1, 1, modes=8, width=16).to(gpu_device)
+    x1 = torch.randn(2, 1, 256, device=gpu_device)
+    with torch.no_grad():
+        e1 = m1(x1)
+    assert _rel(e1, m1(x1.requires_grad_(True)).detach()) < 2e-6
