@@ -58,6 +58,10 @@ int rpde_plan_create(rpde_plan** plan, int n, int modes, int norm, void* stream)
 int rpde_plan_destroy(rpde_plan* plan);
 /* copies of the float tables for tests: analysis [2*kp, ldn], synthesis [n, 2*kp] */
 int rpde_plan_info(const rpde_plan* plan, int* n, int* modes, int* kp, int* ldn);
+/* number of plans the per-process cache holds (every spectral entry point below takes its plans from that cache and
+ * builds a missing one on first use: hipMalloc + one stream synchronisation).  Constant across training steps once
+ * rpde.ops.warm_plans() has seen the run's grid sizes. */
+int rpde_plan_cache_count(void);
 int rpde_plan_tables(const rpde_plan* plan, float* analysis_host, float* synthesis_host);
 
 /* ---- generic strided batched GEMM (fp32 MFMA) -----------------------------

@@ -168,6 +168,25 @@ def _lin(lo: float, hi: float, n: int) -> Tensor:
 # --------------------------------------------------------------------------
 # FNO1d / FNO2d forward  (models/fno.py:56-76, 130-150; fno_blocks.py)
 # --------------------------------------------------------------------------
+def fno_block(sd: Mapping[str, Tensor], x: Tensor, prefix: str = "", activation: str = "gelu") -> Tensor:
+    """FNOBlock1d / FNOBlock2d (models/fno_blocks.py:25-33, 63-71): act(spectral_conv(x) + bypass 1x1 conv(x));
+    the rank of x picks the 1-D or 2-D pair"""
+    if x.dim() == 3:
+        s = spectral_conv1d(x, sd[prefix + "spectral_conv.weights1"])
+        c = F.conv1d(x, sd[prefix + "bypass_conv.weight"], sd[prefix + "bypass_conv.bias"])
+    else:
+        s = spectral_conv2d(x, sd[prefix + "spectral_conv.weights1"], sd[prefix + "spectral_conv.weights2"])
+        c = F.conv2d(x, sd[prefix + "bypass_conv.weight"], sd[prefix + "bypass_conv.bias"])
+    return _act(activation)(s + c)
+
+
+def conv_mlp(sd: Mapping[str, Tensor], x: Tensor, prefix: str = "") -> Tensor:
+    """MLP1d / MLP2d (models/fno_blocks.py:35-45, 73-83): 1x1 conv -> GELU -> 1x1 conv"""
+    conv = F.conv1d if x.dim() == 3 else F.conv2d
+    h = F.gelu(conv(x, sd[prefix + "mlp1.weight"], sd[prefix + "mlp1.bias"]))
+    return conv(h, sd[prefix + "mlp2.weight"], sd[prefix + "mlp2.bias"])
+
+
 def fno1d_forward(sd: Mapping[str, Tensor], x: Tensor, n_blocks: int = 4,
                   activation: str = "relu") -> Tensor:
     b, _, n = x.shape
@@ -176,12 +195,8 @@ def fno1d_forward(sd: Mapping[str, Tensor], x: Tensor, n_blocks: int = 4,
     h = F.conv1d(h, sd["lifting.weight"], sd["lifting.bias"])
     act = _act(activation)
     for i in range(n_blocks):
-        p = f"fno_blocks.{i}."
-        h = act(spectral_conv1d(h, sd[p + "spectral_conv.weights1"])
-                + F.conv1d(h, sd[p + "bypass_conv.weight"], sd[p + "bypass_conv.bias"]))
-    h = F.conv1d(h, sd["projection.mlp1.weight"], sd["projection.mlp1.bias"])
-    h = F.gelu(h)
-    return F.conv1d(h, sd["projection.mlp2.weight"], sd["projection.mlp2.bias"])
+        h = fno_block(sd, h, f"fno_blocks.{i}.", activation)
+    return conv_mlp(sd, h, "projection.")
 
 
 def fno2d_forward(sd: Mapping[str, Tensor], x: Tensor, n_blocks: int = 4,
@@ -191,14 +206,9 @@ def fno2d_forward(sd: Mapping[str, Tensor], x: Tensor, n_blocks: int = 4,
     gy = _lin(0.0, 1.0, n).reshape(1, 1, 1, n).repeat(b, 1, m, 1)
     h = torch.cat((x, gx, gy), dim=1)
     h = F.conv2d(h, sd["lifting.weight"], sd["lifting.bias"])
-    act = _act(activation)
     for i in range(n_blocks):
-        p = f"fno_blocks.{i}."
-        h = act(spectral_conv2d(h, sd[p + "spectral_conv.weights1"], sd[p + "spectral_conv.weights2"])
-                + F.conv2d(h, sd[p + "bypass_conv.weight"], sd[p + "bypass_conv.bias"]))
-    h = F.conv2d(h, sd["projection.mlp1.weight"], sd["projection.mlp1.bias"])
-    h = F.gelu(h)
-    return F.conv2d(h, sd["projection.mlp2.weight"], sd["projection.mlp2.bias"])
+        h = fno_block(sd, h, f"fno_blocks.{i}.", activation)
+    return conv_mlp(sd, h, "projection.")
 
 
 # --------------------------------------------------------------------------

@@ -188,6 +188,11 @@ extern "C" {
 const char* rpde_last_error(void) { return rpde::g_err.c_str(); }
 int rpde_version(void) { return 100; }
 
+int rpde_plan_cache_count(void) {
+  std::lock_guard<std::mutex> lk(rpde::g_mu);
+  return (int)rpde::g_cache.size();
+}
+
 int rpde_plan_create(rpde_plan** plan, int n, int modes, int norm, void* stream) {
   if (!plan) { rpde::set_error("plan_create: null out pointer"); return RPDE_ERR_ARG; }
   int keff = modes < n / 2 + 1 ? modes : n / 2 + 1;

@@ -293,8 +293,14 @@ int rpde_linear_bwd(const float* x, const float* w, const float* grad_out, float
 
 // --------------------------- 1x1 conv, channels-first -----------------------
 // out[b][Cout,S] (+)= W[Cout,Cin] . act_in(x[b])[Cin,S] + bias
+// weight gradient: one slab per (batch entry, reduction split); the split only when the batch alone leaves the chip idle
+static int conv1x1_ksplit(int B, int64_t S) {
+  int ks = 1;
+  while (ks < 8 && B * ks < 64 && S / (2 * ks) >= 128) ks *= 2;
+  return ks;
+}
 size_t rpde_conv1x1_ws_bytes(int B, int Cin, int Cout, int64_t S) {
-  return arena_bytes((size_t)B * Cout * Cin) + arena_bytes((size_t)B * Cout * 64);
+  return arena_bytes((size_t)B * conv1x1_ksplit(B, S) * Cout * Cin) + arena_bytes((size_t)B * Cout * 64);
 }
 
 int rpde_conv1x1_fwd(const float* x, const float* w, const float* b, float* out, int B, int Cin, int Cout, int64_t S,
@@ -318,23 +324,31 @@ int rpde_conv1x1_act_fwd(const float* x, const float* w, const float* b, float* 
 }
 
 namespace rpde {
-// gb[c] = sum_{b,s} g[b][c][s]: rows (b,c) of length S -> per-row partial sums, then fold over b
-__global__ __launch_bounds__(256) void k_rowsum64(const float* __restrict__ g, float* __restrict__ part, long S) {
-  // one block per row, 64 partials per row kept for a deterministic second stage
+// gb[c] = sum_{b,s} g[b][c][s]: rows (b,c) of length S -> one sum per row (fixed-shape tree, so the result does
+// not depend on scheduling), then fold over b
+__global__ __launch_bounds__(256) void k_rowsum(const float* __restrict__ g, float* __restrict__ part, long S) {
   __shared__ float red[256];
   const float* r = g + (long)blockIdx.x * S;
   float acc = 0.f;
-  for (long i = threadIdx.x; i < S; i += 256) acc += r[i];
+  if ((S & 3) == 0 && (reinterpret_cast<uintptr_t>(r) & 15) == 0) {
+    const float4* r4 = reinterpret_cast<const float4*>(r);
+    for (long i = threadIdx.x; i < (S >> 2); i += 256) { const float4 v = r4[i]; acc += (v.x + v.y) + (v.z + v.w); }
+  } else {
+    for (long i = threadIdx.x; i < S; i += 256) acc += r[i];
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < 64) part[(long)blockIdx.x * 64 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 __global__ void k_fold_bias(const float* __restrict__ part, float* __restrict__ gb, int B, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b)
-    for (int j = 0; j < 64; ++j) acc += part[((long)b * C + c) * 64 + j];
+  for (int b = 0; b < B; ++b) acc += part[(long)b * C + c];
   gb[c] = acc;
 }
 }  // namespace rpde
@@ -345,7 +359,8 @@ int rpde_conv1x1_bwd(const float* x, const float* w, const float* grad_out, floa
   RPDE_CHECK_ARG(x && w && grad_out && B > 0 && Cin > 0 && Cout > 0 && S > 0 && S < (1L << 31), "conv1x1_bwd: bad arguments");
   hipStream_t st = as_stream(stream);
   Arena ar(ws, ws_bytes);
-  float* slabs = ar.take((size_t)B * Cout * Cin);
+  const int ks = conv1x1_ksplit(B, S);
+  float* slabs = ar.take((size_t)B * ks * Cout * Cin);
   float* part = ar.take((size_t)B * Cout * 64);
   if (!ar.ok()) { set_error("conv1x1_bwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
   if (grad_w) {
@@ -355,13 +370,14 @@ int rpde_conv1x1_bwd(const float* x, const float* w, const float* grad_out, floa
     d.B = x; d.b_kmajor = 1; d.ldb = S;
     d.C = slabs; d.ldc = Cin;
     d.M = Cout; d.N = Cin; d.K = (int)S;
-    d.batch = B; d.sA1 = (long)Cout * S; d.sB1 = (long)Cin * S; d.sC1 = (long)Cout * Cin;
+    d.batch = B; d.sA1 = (long)Cout * S; d.sB1 = (long)Cin * S; d.sC1 = (long)ks * Cout * Cin;
+    d.ksplit = ks; d.sCk = (long)Cout * Cin;
     d.act_b = act_in;
     RPDE_TRY(launch_gemm(d, st));
-    RPDE_TRY(reduce_slabs(slabs, grad_w, (long)Cout * Cin, B, (long)Cout * Cin, 1.f, 0, st));
+    RPDE_TRY(reduce_slabs(slabs, grad_w, (long)Cout * Cin, B * ks, (long)Cout * Cin, 1.f, 0, st));
   }
   if (grad_b) {
-    hipLaunchKernelGGL(k_rowsum64, dim3(B * Cout), dim3(256), 0, st, grad_out, part, (long)S);
+    hipLaunchKernelGGL(k_rowsum, dim3(B * Cout), dim3(256), 0, st, grad_out, part, (long)S);
     RPDE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_fold_bias, dim3((Cout + 63) / 64), dim3(64), 0, st, part, grad_b, B, Cout);
     RPDE_LAUNCH_CHECK();

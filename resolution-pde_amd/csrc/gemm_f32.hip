@@ -53,6 +53,10 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
     if (bm == 32) { BMc = 32; BNc = 128; }
     else if (bn == 32) { BMc = 128; BNc = 32; }
     else { BMc = bm; BNc = bn; }
+    // small problems (the 1-D configurations): 128x128 tiles would leave most of the 256 CUs idle
+    static const bool small_tiles = [] { const char* e = getenv("RPDE_SMALL_TILES"); return !(e && e[0] == '0'); }();
+    if (small_tiles && BMc == 128 && BNc == 128 && !d.colsum &&
+        (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit < 128) { BMc = 64; BNc = 64; }
   }
   g.mtiles = (d.M + BMc - 1) / BMc;
   g.ntiles = (d.N + BNc - 1) / BNc;

@@ -28,98 +28,186 @@ __device__ __forceinline__ const float* wsel(const float* w1, const float* w2, c
   return w + ((((long)i * g.Co + o) * g.m1 + rr) * g.m2 + ky) * 2;
 }
 
-__global__ void k_cmix_fwd(const float* __restrict__ s, const float* __restrict__ w1, const float* __restrict__ w2,
-                           float* __restrict__ out, MixGeom g) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long tot = (long)g.B * g.Co * g.R * g.m2;
-  if (idx >= tot) return;
-  const int ky = (int)(idx % g.m2);
-  const int r = (int)((idx / g.m2) % g.R);
-  const int o = (int)((idx / ((long)g.m2 * g.R)) % g.Co);
-  const int b = (int)(idx / ((long)g.m2 * g.R * g.Co));
-  const long blk = 2L * g.R * g.kp;
-  float ar = 0.f, ai = 0.f;
-  for (int i = 0; i < g.Ci; ++i) {
-    const float* sp = s + ((long)b * g.Ci + i) * blk + (2L * r) * g.kp + ky;
-    const float xr = sp[0], xi = sp[g.kp];
-    const float* w = wsel(w1, w2, g, i, o, r, ky);
-    ar += xr * w[0] - xi * w[1];
-    ai += xr * w[1] + xi * w[0];
+// ---- per-mode complex channel mixing (compl_mul1d / complex_mul2d of the reference, spectral_convolution.py:34-36,
+// ---- 75-77) and its two adjoints, one template:
+//   MODE 0  out[b,o] = sum_i s[b,i] W[i,o]            (reduction over i, 'a' = input spectra  [B,Ci], 'c' -> [B,Co])
+//   MODE 1  ds[b,i]  = sum_o g[b,o] conj(W[i,o])      (reduction over o, 'a' = output grads   [B,Co], 'c' -> [B,Ci])
+//   MODE 2  gW[i,o]  = sum_b conj(s[b,i]) g[b,o]      (reduction over b)
+// per retained mode (r, ky).  A wave owns one (row r, kept channel) pair: lanes 0..15 of each 16-lane group are 16
+// consecutive ky (the contiguous index of both the spectra and the weights: 64 / 128-byte coalesced segments), the
+// four lane groups split the reduction index four ways and are combined with two wave shuffles at the end.  The
+// eight waves of a workgroup share one row r of the spectra, staged in LDS in chunks of the reduction index, so the
+// spectra are read from memory once per workgroup and every weight exactly once per launch.
+constexpr int CMIX_WAVES = 8;
+constexpr int CMIX_LDS_FLOATS = 8192;          // 32 KB of staged spectra per chunk
+
+template <int MODE, int MAXB>
+__global__ __launch_bounds__(64 * CMIX_WAVES) void k_cmix(const float* __restrict__ a, const float* __restrict__ a2,
+                                                            const float* __restrict__ w1, const float* __restrict__ w2,
+                                                            float* __restrict__ c, float* __restrict__ c2, MixGeom g) {
+  __shared__ float stage[CMIX_LDS_FLOATS];
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, grp = l >> 4, kl = l & 15;
+  const int nwaves = blockDim.x >> 6;               // 8, or 4 when there are few (row, channel, slab) triples
+  const int r = blockIdx.y;
+  const long blk = 2L * g.R * g.kp;                     // floats per (b, channel) spectrum block
+  if (MODE != 2) {
+    // batch slab blockIdx.z: MAXB samples whose accumulators a lane keeps in registers
+    const int b0 = blockIdx.z * MAXB;
+    a += (long)b0 * (MODE == 0 ? g.Ci : g.Co) * blk;
+    c += (long)b0 * (MODE == 0 ? g.Co : g.Ci) * blk;
+    g.B = min(MAXB, g.B - b0);
   }
-  float* op = out + ((long)b * g.Co + o) * blk + (2L * r) * g.kp + ky;
-  op[0] = ar;
-  op[g.kp] = ai;
+  // kept index of this wave (the one that is neither reduced nor ky): o (MODE 0), i (MODE 1), (i,o) pair (MODE 2)
+  const int nkept = MODE == 0 ? g.Co : (MODE == 1 ? g.Ci : g.Ci * g.Co);
+  const int nred = MODE == 0 ? g.Ci : (MODE == 1 ? g.Co : g.B);
+  const int kept = blockIdx.x * nwaves + wv;
+  const bool live = kept < nkept;
+  for (int ky0 = 0; ky0 < g.m2; ky0 += 16) {
+    const int ky = ky0 + kl;
+    const bool kyok = ky < g.m2;
+    float accr[MODE == 2 ? 1 : MAXB], acci[MODE == 2 ? 1 : MAXB];
+#pragma unroll
+    for (int b = 0; b < (MODE == 2 ? 1 : MAXB); ++b) { accr[b] = 0.f; acci[b] = 0.f; }
+    if (MODE == 2) {
+      // no staging: each wave needs one (i, o) pair of columns only
+      if (live && kyok) {
+        const int i = kept / g.Co, o = kept % g.Co;
+        for (int b = grp; b < g.B; b += 4) {
+          const float* sp = a + ((long)b * g.Ci + i) * blk + (2L * r) * g.kp + ky;
+          const float* gp = a2 + ((long)b * g.Co + o) * blk + (2L * r) * g.kp + ky;
+          const float xr = sp[0], xi = sp[g.kp], gr = gp[0], gi = gp[g.kp];
+          accr[0] += xr * gr + xi * gi;
+          acci[0] += xr * gi - xi * gr;
+        }
+      }
+    } else {
+      // chunks of the reduction channel index: stage a[b][ch][row r][re|im][16 ky] for all b
+      const int per_ch = g.B * 32;                                   // floats per reduction channel in the stage
+      const int chunk = max(4, min(nred, (CMIX_LDS_FLOATS / per_ch) & ~3));
+      for (int c0 = 0; c0 < nred; c0 += chunk) {
+        const int nc = min(chunk, nred - c0);
+        __syncthreads();
+        for (int e = tid; e < nc * per_ch; e += blockDim.x) {
+          const int kk = e & 15, ri = (e >> 4) & 1, b = (e >> 5) % g.B, ch = e / per_ch;
+          const int kyy = ky0 + kk;
+          stage[e] = kyy < g.m2 ? a[((long)b * nred + c0 + ch) * blk + (2L * r + ri) * g.kp + kyy] : 0.f;
+        }
+        __syncthreads();
+        if (live && kyok) {
+          for (int ch = grp; ch < nc; ch += 4) {
+            const int red = c0 + ch;
+            const int i = MODE == 0 ? red : kept, o = MODE == 0 ? kept : red;
+            const float* w = wsel(w1, w2, g, i, o, r, ky);
+            const float wr = w[0], wi = MODE == 0 ? w[1] : -w[1];     // adjoint: conj(W)
+            const float* sp = stage + ch * per_ch + kl;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) {
+              if (b < g.B) {
+                const float xr = sp[b * 32], xi = sp[b * 32 + 16];
+                accr[b] += xr * wr - xi * wi;
+                acci[b] += xr * wi + xi * wr;
+              }
+            }
+          }
+        }
+      }
+    }
+    // combine the four lane groups (reduction index mod 4)
+#pragma unroll
+    for (int b = 0; b < (MODE == 2 ? 1 : MAXB); ++b) {
+      accr[b] += __shfl_xor(accr[b], 16, 64); accr[b] += __shfl_xor(accr[b], 32, 64);
+      acci[b] += __shfl_xor(acci[b], 16, 64); acci[b] += __shfl_xor(acci[b], 32, 64);
+    }
+    if (live && kyok && grp == 0) {
+      if (MODE == 2) {
+        const int i = kept / g.Co, o = kept % g.Co;
+        float* gw = r < g.m1 ? c : c2;
+        const int rr = r < g.m1 ? r : r - g.m1;
+        float* p = gw + ((((long)i * g.Co + o) * g.m1 + rr) * g.m2 + ky) * 2;
+        p[0] = accr[0];
+        p[1] = acci[0];
+      } else {
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+          if (b < g.B) {
+            float* op = c + ((long)b * nkept + kept) * blk + (2L * r) * g.kp + ky;
+            op[0] = accr[b];
+            op[g.kp] = acci[b];
+          }
+        }
+      }
+    }
+  }
 }
 
-// ds[b,i] = sum_o g[b,o] * conj(W[i,o])
-__global__ void k_cmix_bwd_data(const float* __restrict__ gsp, const float* __restrict__ w1, const float* __restrict__ w2,
-                                float* __restrict__ ds, MixGeom g) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long tot = (long)g.B * g.Ci * g.R * g.m2;
-  if (idx >= tot) return;
-  const int ky = (int)(idx % g.m2);
-  const int r = (int)((idx / g.m2) % g.R);
-  const int i = (int)((idx / ((long)g.m2 * g.R)) % g.Ci);
-  const int b = (int)(idx / ((long)g.m2 * g.R * g.Ci));
-  const long blk = 2L * g.R * g.kp;
-  float ar = 0.f, ai = 0.f;
-  for (int o = 0; o < g.Co; ++o) {
-    const float* gp = gsp + ((long)b * g.Co + o) * blk + (2L * r) * g.kp + ky;
-    const float gr = gp[0], gi = gp[g.kp];
-    const float* w = wsel(w1, w2, g, i, o, r, ky);
-    ar += gr * w[0] + gi * w[1];
-    ai += gi * w[0] - gr * w[1];
-  }
-  float* dp = ds + ((long)b * g.Ci + i) * blk + (2L * r) * g.kp + ky;
-  dp[0] = ar;
-  dp[g.kp] = ai;
-}
-
-// gW[i,o] = sum_b conj(s[b,i]) * g[b,o]
-__global__ void k_cmix_bwd_w(const float* __restrict__ s, const float* __restrict__ gsp, float* __restrict__ gw1,
-                             float* __restrict__ gw2, MixGeom g) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long tot = (long)g.Ci * g.Co * g.R * g.m2;
-  if (idx >= tot) return;
-  const int ky = (int)(idx % g.m2);
-  const int r = (int)((idx / g.m2) % g.R);
-  const int o = (int)((idx / ((long)g.m2 * g.R)) % g.Co);
-  const int i = (int)(idx / ((long)g.m2 * g.R * g.Co));
-  const long blk = 2L * g.R * g.kp;
-  float ar = 0.f, ai = 0.f;
-  for (int b = 0; b < g.B; ++b) {
-    const float* sp = s + ((long)b * g.Ci + i) * blk + (2L * r) * g.kp + ky;
-    const float* gp = gsp + ((long)b * g.Co + o) * blk + (2L * r) * g.kp + ky;
-    const float xr = sp[0], xi = sp[g.kp], gr = gp[0], gi = gp[g.kp];
-    ar += xr * gr + xi * gi;
-    ai += xr * gi - xi * gr;
-  }
-  float* gw = r < g.m1 ? gw1 : gw2;
-  const int rr = r < g.m1 ? r : r - g.m1;
-  float* p = gw + ((((long)i * g.Co + o) * g.m1 + rr) * g.m2 + ky) * 2;
-  p[0] = ar;
-  p[1] = ai;
+template <int MODE, int MAXB>
+static void launch_cmix(const float* a, const float* w1, const float* w2, float* out, const MixGeom& g, int nout, int nw,
+                        hipStream_t st) {
+  const dim3 grid((nout + nw - 1) / nw, g.R, (g.B + MAXB - 1) / MAXB);
+  hipLaunchKernelGGL((k_cmix<MODE, MAXB>), grid, dim3(64 * nw), 0, st, a, nullptr, w1, w2, out, nullptr, g);
 }
 
 static int launch_mix(int which, const float* a, const float* b, const float* w1, const float* w2, float* out, float* out2,
-                      const MixGeom& g, hipStream_t st) {
-  long tot;
-  if (which == 0) { tot = (long)g.B * g.Co * g.R * g.m2; hipLaunchKernelGGL(k_cmix_fwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, w1, w2, out, g); }
-  else if (which == 1) { tot = (long)g.B * g.Ci * g.R * g.m2; hipLaunchKernelGGL(k_cmix_bwd_data, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, w1, w2, out, g); }
-  else { tot = (long)g.Ci * g.Co * g.R * g.m2; hipLaunchKernelGGL(k_cmix_bwd_w, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, b, out, out2, g); }
+                      const MixGeom& g0, hipStream_t st) {
+  if (which == 2) {
+    const dim3 grid((g0.Ci * g0.Co + CMIX_WAVES - 1) / CMIX_WAVES, g0.R);
+    hipLaunchKernelGGL((k_cmix<2, 1>), grid, dim3(64 * CMIX_WAVES), 0, st, a, b, w1, w2, out, out2, g0);
+    RPDE_LAUNCH_CHECK();
+    return RPDE_OK;
+  }
+  // MODE 0 / 1 keep one batch slab of accumulators in registers; slabs run along grid.z.  The slab is 16 samples
+  // unless that leaves most of the chip idle (the 1-D layers: R = 1, a handful of channel groups): then 4 or 2, and
+  // as a last step half-size workgroups -- every workgroup stages only its own slab, so smaller slabs cost no
+  // extra spectrum traffic, only more reads of the (L2-resident) weights.
+  const int nout = which == 0 ? g0.Co : g0.Ci;
+  auto blocks = [&](int maxb, int nw) { return (long)((nout + nw - 1) / nw) * g0.R * ((g0.B + maxb - 1) / maxb); };
+  int maxb = 16, nw = CMIX_WAVES;
+  if (blocks(16, nw) < 64) maxb = blocks(4, nw) >= 64 ? 4 : 2;
+  if (blocks(maxb, nw) < 64) nw = 4;
+#define RPDE_CMIX(MB) (which == 0 ? launch_cmix<0, MB>(a, w1, w2, out, g0, nout, nw, st) : launch_cmix<1, MB>(a, w1, w2, out, g0, nout, nw, st))
+  if (maxb == 16) RPDE_CMIX(16);
+  else if (maxb == 4) RPDE_CMIX(4);
+  else RPDE_CMIX(2);
+#undef RPDE_CMIX
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;
 }
 
+// Thin products -- a long reduction onto few output tiles (the 1-D layers at small batch: [1024 x 1024] . [1024 x 32]
+// is 8 workgroups) -- split the reduction over the grid into slabs and fold them in fixed order; `slabs` is the
+// caller's scratch of thin_slab_floats() entries (nullptr: never split).
+static int thin_ksplit(long rows, int ncols, int kred) {
+  if (ncols > 32 || kred < 256) return 1;
+  const long tiles = (rows + 127) / 128;
+  if (tiles >= 64) return 1;
+  int ks = 1;
+  while (ks < 16 && tiles * ks < 64 && kred / (2 * ks) >= 64) ks *= 2;
+  return ks;
+}
+static size_t thin_slab_floats(long rows, int ncols, int kred) {
+  const int ks = thin_ksplit(rows, ncols, kred);
+  return ks > 1 ? (size_t)ks * rows * ncols : 0;
+}
+static int thin_gemm(rpde_gemm_desc& d, float* slabs, hipStream_t st) {
+  const int ks = slabs ? thin_ksplit(d.M, d.N, d.K) : 1;
+  if (ks == 1 || d.ldc != d.N) return launch_gemm(d, st);
+  float* out = d.C;
+  const float alpha = d.alpha;
+  d.C = slabs; d.ksplit = ks; d.sCk = (long)d.M * d.N; d.alpha = 1.f;
+  RPDE_TRY(launch_gemm(d, st));
+  return reduce_slabs(slabs, out, (long)d.M * d.N, ks, (long)d.M * d.N, alpha, 0, st);
+}
+
 // rows x n  ->  rows x 2kp   (forward real DFT along the contiguous axis), optional act on the input
-static int cf_analysis(const rpde_plan* pl, const float* x, float* spec, long rows, int n, int act_in, hipStream_t st) {
+static int cf_analysis(const rpde_plan* pl, const float* x, float* spec, long rows, int n, int act_in, hipStream_t st,
+                       float* slabs = nullptr) {
   if (!act_in && pl->cf_ana[0] && rows >= 16 && cf_h2_eligible(n, 2 * pl->kp)) return cf_analysis_h2(pl, 0, x, spec, rows, 1.f, st);
   rpde_gemm_desc d = gemm_desc();
   d.A = x; d.a_kmajor = 1; d.lda = n; d.act_a = act_in;
   d.B = pl->fa; d.b_kmajor = 1; d.ldb = pl->ldn;
   d.C = spec; d.ldc = 2L * pl->kp;
   d.M = (int)rows; d.N = 2 * pl->kp; d.K = n;
-  return launch_gemm(d, st);
+  return thin_gemm(d, slabs, st);
 }
 // rows x 2kp -> rows x n  (C2R synthesis)
 static int cf_synthesis(const rpde_plan* pl, const float* spec, float* out, long rows, int n, hipStream_t st,
@@ -134,14 +222,15 @@ static int cf_synthesis(const rpde_plan* pl, const float* spec, float* out, long
   return launch_gemm(d, st);
 }
 // adjoint of synthesis: g[rows,n] . Fs -> [rows, 2kp]
-static int cf_synthesis_T(const rpde_plan* pl, const float* g, float* gspec, long rows, int n, hipStream_t st) {
+static int cf_synthesis_T(const rpde_plan* pl, const float* g, float* gspec, long rows, int n, hipStream_t st,
+                          float* slabs = nullptr) {
   if (pl->cf_ana[1] && rows >= 16 && cf_h2_eligible(n, 2 * pl->kp)) return cf_analysis_h2(pl, 1, g, gspec, rows, 1.f, st);
   rpde_gemm_desc d = gemm_desc();
   d.A = g; d.a_kmajor = 1; d.lda = n;
   d.B = pl->fs; d.b_kmajor = 0; d.ldb = 2L * pl->kp;
   d.C = gspec; d.ldc = 2L * pl->kp;
   d.M = (int)rows; d.N = 2 * pl->kp; d.K = n;
-  return launch_gemm(d, st);
+  return thin_gemm(d, slabs, st);
 }
 // adjoint of analysis: dspec[rows,2kp] . Fa -> gx[rows,n], through act'(x) when act_in
 static int cf_analysis_T(const rpde_plan* pl, const float* dspec, float* gx, long rows, int n, int act_in, const float* x,
@@ -178,8 +267,8 @@ extern "C" {
 size_t rpde_spectral1d_ws_bytes(int B, int Cin, int Cout, int n, int K) {
   const int kp = (K + 3) / 4 * 4;
   const int cm = Cin > Cout ? Cin : Cout;
-  (void)n;
-  return 2 * arena_bytes((size_t)B * cm * 2 * kp);
+  const size_t a = thin_slab_floats((long)B * Cin, 2 * kp, n), b = thin_slab_floats((long)B * Cout, 2 * kp, n);
+  return 2 * arena_bytes((size_t)B * cm * 2 * kp) + arena_bytes(a > b ? a : b);
 }
 
 int rpde_spectral1d_fwd(const float* x, const float* w, float* out, float* spec_in, int B, int Cin, int Cout, int n, int K,
@@ -191,8 +280,10 @@ int rpde_spectral1d_fwd(const float* x, const float* w, float* out, float* spec_
   RPDE_TRY(get_plan(&pl, n, K, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));
   Arena ar(ws, ws_bytes);
   float* ospec = ar.take((size_t)B * Cout * 2 * pl->kp);
+  const size_t nslab = thin_slab_floats((long)B * Cin, 2 * pl->kp, n);
+  float* slabs = nslab ? ar.take(nslab) : nullptr;
   if (!ar.ok()) { set_error("spectral1d_fwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
-  RPDE_TRY(cf_analysis(pl, x, spec_in, (long)B * Cin, n, act_in, st));
+  RPDE_TRY(cf_analysis(pl, x, spec_in, (long)B * Cin, n, act_in, st, slabs));
   if (pl->kp != K) RPDE_HIP(hipMemsetAsync(ospec, 0, sizeof(float) * (size_t)B * Cout * 2 * pl->kp, st));
   MixGeom g{B, Cin, Cout, 1, 1, K, pl->kp};
   RPDE_TRY(launch_mix(0, spec_in, nullptr, w, w, ospec, nullptr, g, st));
@@ -211,8 +302,10 @@ int rpde_spectral1d_bwd(const float* grad_out, const float* spec_in, const float
   Arena ar(ws, ws_bytes);
   float* gspec = ar.take((size_t)B * Cout * 2 * pl->kp);
   float* dspec = ar.take((size_t)B * Cin * 2 * pl->kp);
+  const size_t nslab = thin_slab_floats((long)B * Cout, 2 * pl->kp, n);
+  float* slabs = nslab ? ar.take(nslab) : nullptr;
   if (!ar.ok()) { set_error("spectral1d_bwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
-  RPDE_TRY(cf_synthesis_T(pl, grad_out, gspec, (long)B * Cout, n, st));
+  RPDE_TRY(cf_synthesis_T(pl, grad_out, gspec, (long)B * Cout, n, st, slabs));
   MixGeom g{B, Cin, Cout, 1, 1, K, pl->kp};
   if (grad_w) RPDE_TRY(launch_mix(2, spec_in, gspec, nullptr, nullptr, grad_w, grad_w, g, st));
   if (grad_x) {

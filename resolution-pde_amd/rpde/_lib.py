@@ -66,6 +66,7 @@ _PP = C.POINTER(C.c_void_p)
 _SIGNATURES = {
     "rpde_last_error": (C.c_char_p, []),
     "rpde_version": (_I, []),
+    "rpde_plan_cache_count": (_I, []),
     "rpde_plan_create": (_I, [C.POINTER(_P), _I, _I, _I, _P]),
     "rpde_plan_destroy": (_I, [_P]),
     "rpde_plan_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

@@ -45,12 +45,21 @@ def run(dims: int, argv=None):
 
     seed = int(args.training.get("seed", 0))
     bs = int(args.training.batch_size)
-    x_normalizer = y_normalizer = None
-    if args.dataset.get("dataset_params"):                     # reference main_2d.py:72-73
+    x_normalizer = y_normalizer = min_data = max_data = min_model = max_model = rollout_set = None
+    normalization_type = "simple"
+    if args.dataset.get("dataset_params"):
+        # reference main_2d.py:72-82: (train, val, test, *stats); main_1d.py:69-80: (train, val, test, rollout, *stats).
+        # stats are (x_normalizer, y_normalizer) or, for Burgers' "minmax", (min_data, max_data, min_model, max_model)
         data_ = instantiate(args.dataset.dataset_params)
         train_set, val_set, test_set = data_[:3]
-        if len(data_) >= 5:
-            x_normalizer, y_normalizer = data_[3], data_[4]
+        if dims == 1:
+            rollout_set = data_[3]
+        stats = data_[4 if dims == 1 else 3:]
+        if len(stats) == 4:
+            normalization_type = "minmax"
+            min_data, max_data, min_model, max_model = stats
+        elif len(stats) == 2:
+            x_normalizer, y_normalizer = stats
     else:
         train_set = markov_pairs(args.dataset.resolutions, dims, seed)
         top = max(int(r) for r in dict(args.dataset.resolutions))
@@ -69,6 +78,15 @@ def run(dims: int, argv=None):
         state = torch.load(ckpt, map_location=device, weights_only=True)
         model.load_state_dict(state["model_state_dict"])
 
+    # plans for every grid the run will meet -- the training / validation / test groups and the post-training sweep
+    # [32 .. max] -- before the first step (no hipMalloc / stream sync inside the training loop)
+    from rpde.ops import warm_plans
+    from utils.resize_utils import get_lower_resolutions
+    seen = {r for ld in (train_loader, val_loader, test_loader) for r in ld.resolution_groups}
+    if seen:
+        seen |= set(get_lower_resolutions(max(seen), min(32, max(seen))))
+        warm_plans(model, seen, dims, in_channels=int(train_set[0][0].shape[0]), device=device)
+
     lr = float(args.training.learning_rate)
     if dims == 2:     # reference main_2d.py:173-174
         optimizer = optim.AdamW(model.parameters(), lr=lr)
@@ -86,7 +104,8 @@ def run(dims: int, argv=None):
                                 use_normalizer=bool(args.training.use_normalizer), epochs=int(args.training.epochs),
                                 device=device)
     torch.cuda.synchronize()
-    test_l2 = evaluate(model, test_loader, normalization_type="simple", y_normalizer=y_normalizer, device=device)
+    test_l2 = evaluate(model, test_loader, normalization_type=normalization_type, min_data=min_data, max_data=max_data,
+                       min_model=min_model, max_model=max_model, y_normalizer=y_normalizer, device=device)
     if rank == 0:
         print(json.dumps({"train_seconds": round(time.time() - t0, 3), "final_train_loss": loss_hist[-1],
                           "final_val_loss": val_hist[-1], "test_rel_l2": test_l2}), flush=True)
@@ -94,29 +113,65 @@ def run(dims: int, argv=None):
     # ---- the reference's post-training sequence: every resolution [32, .., max] (main_2d.py:287, main_1d.py:250),
     # ---- and in 1-D the autoregressive rollout (main_1d.py:272; utils/autoregressive_step.py:284-309)
     from utils.resize_utils import evaluate_all_resolutions, to_resolution
-    tx = torch.stack([test_set[i][0] for i in range(len(test_set))])
-    ty = torch.stack([test_set[i][1] for i in range(len(test_set))])
-    top_res = int(tx.shape[-1])
+    dp = args.dataset.get("dataset_params") or {}
+    raw_eval = None
+    if dp.get("eval_dataset_target") and args.dataset.get("train_mres"):
+        # multi-resolution training evaluates on ONE single-resolution file through another loader (reference
+        # utils/naive_utils.py:322-350): un-normalised pairs, encoded here with the training statistics
+        keep = ("reduced_batch", "reduced_resolution_t", "use_low_pass_filter", "lowpass_cutoff_ratio", "num_samples_max")
+        node = {"_target_": dp["eval_dataset_target"], "filename": dp["eval_filename"],
+                "saved_folder": dp.get("eval_saved_folder", dp.get("saved_folder")), "data_normalizer": False,
+                **{k: dp[k] for k in keep if k in dp}}
+        raw_eval = instantiate(node)[2]
+    pairs = [(raw_eval or test_set)[i] for i in range(len(raw_eval or test_set))]
+    top_res = max(int(x.shape[-1]) for x, _ in pairs)
+    pairs = [(torch.as_tensor(x), torch.as_tensor(y)) for x, y in pairs if int(x.shape[-1]) == top_res]   # a mixed test
+    tx, ty = torch.stack([x for x, _ in pairs]), torch.stack([y for _, y in pairs])        # split: highest resolution only
+    if raw_eval is not None and x_normalizer is not None:
+        tx, ty = x_normalizer.encode(tx), y_normalizer.encode(ty)
     how = str(args.dataset.get("evaluation_type", "naive_downsample"))
-    dec = (lambda t: y_normalizer.decode(t, device=device)) if y_normalizer is not None else None   # noqa: E731
+    if y_normalizer is not None:
+        dec = lambda t: y_normalizer.decode(t, device=device)                                    # noqa: E731
+    elif min_model is not None:
+        dec = lambda t: t * (max_model - min_model) + min_model                                  # noqa: E731
+    else:
+        dec = None
     ty_phys = dec(ty.to(device)).cpu() if dec else ty
     resolution_results = evaluate_all_resolutions(model, tx, ty_phys, max_resolution=top_res, min_resolution=min(32, top_res),
                                                   how=how, batch_size=bs, y_decode=dec, device=device)
     rollout_results = None
-    if dims == 1 and not args.dataset.get("dataset_params"):
+    if dims == 1:
         from utils.autoregressive_step import perform_rollout_1d, rollout_loss
-        from utils.synthetic import advance
         steps = int(args.dataset.get("rollout_steps", 4))
-        traj = [tx[rank::world, 0]]
-        for _ in range(steps):
-            traj.append(advance(traj[-1], 1))
-        traj = torch.stack(traj, dim=1).to(device)                           # [n, steps+1, res]
+        if rollout_set is not None and len(rollout_set):
+            # whole test trajectories of the file [T, X], physical units: encode the start, roll in normalised space
+            # (decode with y-statistics, re-encode with x-statistics between steps), compare in physical units
+            steps = min(steps, int(rollout_set[0].shape[0]) - 1)
+            mine = [rollout_set[i] for i in range(rank, len(rollout_set), world)]              # this rank's trajectories
+            phys = (torch.stack(mine)[:, :steps + 1] if mine else torch.zeros(0, steps + 1, top_res)).to(device)
+            if min_data is not None:
+                enc = lambda t: (t - min_data) / (max_data - min_data)                           # noqa: E731
+                from types import SimpleNamespace
+                xn = SimpleNamespace(encode=enc)
+                yn = SimpleNamespace(decode=lambda t, device=None: t * (max_model - min_model) + min_model)
+            else:
+                xn, yn = x_normalizer, y_normalizer
+                enc = xn.encode if xn is not None else (lambda t: t)                             # noqa: E731
+            traj, decode_pred = phys, (lambda t: yn.decode(t, device=device)) if yn is not None else (lambda t: t)
+        else:
+            from utils.synthetic import advance
+            frames = [tx[rank::world, 0]]
+            for _ in range(steps):
+                frames.append(advance(frames[-1], 1))
+            traj = torch.stack(frames, dim=1).to(device)                       # [n, steps+1, res]
+            xn = yn = None
+            enc = decode_pred = lambda t: t                                      # noqa: E731
         acc = torch.zeros(len(resolution_results), 2, dtype=torch.float64, device=device)
         for k, res in enumerate(resolution_results):
             tr = to_resolution(traj, res, "naive_downsample")
             if tr.shape[0]:
-                pred = perform_rollout_1d(model.eval(), tr[:, 0], steps, device=device)
-                acc[k, 0] += rollout_loss(pred, tr) * tr.shape[0]
+                pred = perform_rollout_1d(model.eval(), enc(tr[:, 0]), steps, device=device, x_normalizer=xn, y_normalizer=yn)
+                acc[k, 0] += rollout_loss(decode_pred(pred), tr) * tr.shape[0]
                 acc[k, 1] += tr.shape[0]
         if world > 1:
             dist.all_reduce(acc)

@@ -578,3 +578,17 @@ def resize2d(x: torch.Tensor, out_size) -> torch.Tensor:
     ws = workspace(nws, x.device)
     check(lib.rpde_resize2d(ptr(x), ptr(out), rows, M, N, Mo, No, ws.data_ptr(), nws, stream_ptr()), "resize2d")
     return out
+
+
+def warm_plans(model, resolutions, dims: int, in_channels: int = 1, device="cuda") -> None:
+    """Build every DFT plan (tables, adjoint tables, operand images: hipMalloc + one stream sync each,
+    csrc/core.hip get_plan) and size the workspaces the model needs at the given grid resolutions, with one
+    throw-away forward per resolution -- so that no allocation or synchronisation happens inside a training
+    step, and hipGraph capture never meets a first-use plan.  Leaves parameters and the train/eval flag alone."""
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        for r in sorted({int(r) for r in resolutions}):
+            model(torch.zeros((1, in_channels) + (r,) * dims, device=device))
+    model.train(was_training)
+    torch.cuda.synchronize(device)

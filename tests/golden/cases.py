@@ -69,6 +69,17 @@ CASES = [
          x=(2, 8, 8, 3), seed=461),
     dict(name="wnlinear_plain", kind="WNLinear", ctor=dict(in_features=64, out_features=1, wnorm=False),
          x=(2, 8, 8, 64), seed=462),
+    # ---- FNO building blocks in isolation (also covered through the whole models below) ----
+    dict(name="fnoblock2d_cfg5", kind="FNOBlock2d", ctor=dict(in_channels=32, out_channels=32, modes1=12, modes2=12),
+         x=(2, 32, 64, 64), seed=471, act="gelu"),
+    dict(name="fnoblock2d_rect_relu", kind="FNOBlock2d", ctor=dict(in_channels=6, out_channels=4, modes1=3, modes2=5),
+         x=(2, 6, 12, 20), seed=472, act="relu"),
+    dict(name="fnoblock1d_cfg1", kind="FNOBlock1d", ctor=dict(in_channels=64, out_channels=64, modes=16),
+         x=(4, 64, 1024), seed=473, act="gelu"),
+    dict(name="mlp2d_cfg5", kind="MLP2d", ctor=dict(in_channels=32, out_channels=1, mid_channels=128),
+         x=(2, 32, 64, 64), seed=474),
+    dict(name="mlp1d_small", kind="MLP1d", ctor=dict(in_channels=8, out_channels=3, mid_channels=20),
+         x=(3, 8, 50), seed=475),
     # ---- G5 whole models ---------------------------------------------------
     # default activation is ReLU: at this size some pre-activation lies within fp32 noise of the
     # kink, so the reference's own fp32 and fp64 gradients differ (one sign flip = 3.7e-3 on dx);

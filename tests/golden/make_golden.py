@@ -35,6 +35,7 @@ def _reference_namespace():
                                              FSpectralConv2d)
     from models.custom_layer import FeedForward, WNLinear
     from models.fno import FNO1d, FNO2d
+    from models.fno_blocks import FNOBlock1d, FNOBlock2d, MLP1d, MLP2d
     from models.ffno import FFNO1D, FFNO2D
     from utils.loss import RelativeL2Loss
     from utils.res_utils import resize, resize_1d

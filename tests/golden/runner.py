@@ -17,7 +17,7 @@ from . import synth
 from .cases import MODEL_KINDS
 
 LAYER_KINDS = ("SpectralConv1d", "SpectralConv2d", "FSpectralConv1d", "FSpectralConv2d",
-               "FeedForward", "WNLinear")
+               "FeedForward", "WNLinear", "FNOBlock1d", "FNOBlock2d", "MLP1d", "MLP2d")
 
 
 class Instance:
@@ -115,6 +115,10 @@ class OracleBackend:
             call = lambda x: R.feedforward(x, p, "", c.get("n_layers", 2), c.get("layer_norm", False))
         elif kind == "WNLinear":
             call = lambda x: R.wn_linear(x, p, "")
+        elif kind in ("FNOBlock1d", "FNOBlock2d"):
+            call = lambda x: R.fno_block(p, x, "", case.get("act", "relu" if kind == "FNOBlock1d" else "gelu"))
+        elif kind in ("MLP1d", "MLP2d"):
+            call = lambda x: R.conv_mlp(p, x, "")
         elif kind == "FNO1d":
             call = lambda x: R.fno1d_forward(p, x, c.get("n_blocks", 4), case.get("act", "relu"))
         elif kind == "FNO2d":

@@ -39,6 +39,7 @@ def _namespace():
     from models.custom_layer import FeedForward, WNLinear
     from models.ffno import FFNO1D, FFNO2D
     from models.fno import FNO1d, FNO2d
+    from models.fno_blocks import FNOBlock1d, FNOBlock2d, MLP1d, MLP2d
     from models.spectral_convolution import FSpectralConv1d, FSpectralConv2d, SpectralConv1d, SpectralConv2d
     from utils.loss import RelativeL2Loss
     from utils.res_utils import resize, resize_1d

@@ -254,3 +254,108 @@ def test_main_2d_on_a_file_dataset_with_normalisers(gpu_device, tmp_path, capsys
     import json
     e0 = json.loads([ln for ln in out.splitlines() if '"epoch": 0' in ln][0])
     assert l2 < 1.0 and l2 < e0["val_loss"], (l2, e0)
+
+
+def _smooth_1d(n, res, steps, seed):
+    from utils.synthetic import advance, random_fields
+    frames = [random_fields(n, res, 1, seed=seed)]               # [n,1,res]
+    for _ in range(steps):
+        frames.append(advance(frames[-1], 1))
+    return torch.cat(frames, dim=1).numpy()                      # [n,T,res]
+
+
+def test_main_1d_on_ks_files(gpu_device, tmp_path, capsys):
+    """dataset=ks/ks_naive: three .npz archives with the HDF5 member names -> dataloaders/ks_naive_markov.py; the
+    6-tuple (train, val, test, rollout, x_normalizer, y_normalizer) is unpacked as main_1d.py:71-76 does, the
+    rollout set drives the autoregressive evaluation"""
+    import json
+    import numpy as np
+    from rpde.entry import run
+    for split, name, n, seed in (("train", "KS_train_64.npz", 24, 1), ("valid", "KS_valid.npz", 6, 2), ("test", "KS_test.npz", 6, 3)):
+        u = (_smooth_1d(n, 64, 8, seed) * 2.0 + 0.5).astype(np.float32)
+        np.savez(tmp_path / name, **{f"{split}/pde_9-64": u, f"{split}/x": np.linspace(0, 64, 64, dtype=np.float32)})
+    l2 = run(1, ["model=ffno_1d/ffno_1d", "dataset=ks/ks_naive", "dataset.dataset_params.filename=KS_train_64.npz",
+                 "dataset.dataset_params.val_filename=KS_valid.npz", "dataset.dataset_params.test_filename=KS_test.npz",
+                 f"dataset.dataset_params.saved_folder={tmp_path}", "dataset.dataset_params.reduced_resolution=1",
+                 "dataset.rollout_steps=4", "model.width=16", "model.n_layers=2", "model.n_modes=8", "model.factor=2",
+                 "training.epochs=6", "training.batch_size=16", "training.learning_rate=0.003",
+                 "training.use_normalizer=true", f"checkpoint_dir={tmp_path}"])
+    out = capsys.readouterr().out
+    e0 = json.loads([ln for ln in out.splitlines() if '"epoch": 0' in ln][0])
+    assert l2 < e0["val_loss"], (l2, e0)
+    roll = run.last["rollout_rel_l2"]
+    assert set(roll) == {32, 64} and all(np.isfinite(v) for v in roll.values())
+
+
+@pytest.mark.parametrize("norm", ["simple", "minmax"])
+def test_main_1d_on_burgers_file(gpu_device, tmp_path, capsys, norm):
+    """dataset=burger/burger_naive with both normalisations: "minmax" returns four range values instead of two
+    normalisers (reference burger_naive_markov.py:449-453) and evaluate() de-normalises with them"""
+    import json
+    import numpy as np
+    from rpde.entry import run
+    u = (_smooth_1d(40, 64, 6, 7) * 2.0 + 0.5).astype(np.float32)
+    np.savez(tmp_path / "burgers.npz", **{"tensor": u, "x-coordinate": np.linspace(0, 1, 64, dtype=np.float32)})
+    l2 = run(1, ["model=fno_1d/fno_1d", "dataset=burger/burger_naive", "dataset.dataset_params.filename=burgers.npz",
+                 f"dataset.dataset_params.saved_folder={tmp_path}", "dataset.dataset_params.reduced_resolution=1",
+                 "dataset.dataset_params.reduced_batch=1", f"dataset.dataset_params.normalization_type={norm}",
+                 "dataset.rollout_steps=3", "model.width=16", "model.modes=8", "training.epochs=5",
+                 "training.batch_size=16", "training.learning_rate=0.003", f"checkpoint_dir={tmp_path}"])
+    out = capsys.readouterr().out
+    e0 = json.loads([ln for ln in out.splitlines() if '"epoch": 0' in ln][0])
+    assert np.isfinite(l2) and l2 < 1.5 * e0["val_loss"] + 1.0, (l2, e0)
+    assert all(np.isfinite(v) for v in run.last["rollout_rel_l2"].values())
+
+
+@pytest.mark.parametrize("eval_file", [True, False])
+def test_main_2d_on_true_multires_files(gpu_device, tmp_path, capsys, eval_file):
+    """dataset=ns/ns_naive_true_mres: the north-star dataset module.  Files at 32^2 plus stride-subsampled 16^2
+    samples -> two resolution groups in one training run, every batch single-resolution"""
+    import json
+    import numpy as np
+    from rpde.entry import run
+    from utils.synthetic import advance, random_fields
+    frames = [random_fields(20, 32, 2, seed=5)]
+    for _ in range(6):
+        frames.append(advance(frames[-1], 2))
+    u = (torch.cat(frames, dim=1).numpy() * 3.0 + 1.0).astype(np.float32)         # [N,T,H,W]
+    np.savez(tmp_path / "ns_32_1e-3.npz", u=u)
+    l2 = run(2, ["model=ffno_2d/ffno_2d", "dataset=ns/ns_naive_true_mres", f"dataset.dataset_params.saved_folder={tmp_path}",
+                 "dataset.dataset_params.file_extension=.npz", "dataset.dataset_params.viscosity=1e-3",
+                 "dataset.dataset_params.data_mres_size={32: 20}", "dataset.dataset_params.add_res=[16]",
+                 "dataset.dataset_params.add_res_samples={16: 10}", "dataset.dataset_params.downsample_from_res=32",
+                 "dataset.dataset_params.use_low_pass_filter=false",
+                 "dataset.dataset_params.eval_filename=ns_32_1e-3.npz" if eval_file else "dataset.dataset_params.eval_dataset_target=null",
+                 f"dataset.dataset_params.eval_saved_folder={tmp_path}", "model.width=16", "model.n_layers=2", "model.n_modes=8",
+                 "model.factor=2", "training.epochs=4", "training.batch_size=8", "training.learning_rate=0.003",
+                 "training.use_normalizer=true", f"checkpoint_dir={tmp_path}"])
+    out = capsys.readouterr().out
+    head = json.loads([ln for ln in out.splitlines() if '"train_batches"' in ln][0])
+    assert head["train_batches"] == (16 * 5) // 8 + (8 * 5) // 8                 # 80 pairs at 32^2 + 40 pairs at 16^2
+    assert np.isfinite(l2) and set(run.last["resolution_rel_l2"]) == {32}
+
+
+def test_warm_plans_leaves_no_plan_to_build_inside_a_step(gpu_device):
+    """rpde.ops.warm_plans: after it has seen the run's grids, forward + backward at those grids add nothing to
+    the plan cache (no hipMalloc / stream sync inside a training step); an unseen grid does"""
+    from models.ffno import FFNO2D
+    from models.fno import FNO1d
+    from rpde._lib import load
+    from rpde.ops import warm_plans
+    from utils.loss import RelativeL2Loss
+    lib = load()
+    loss_fn = RelativeL2Loss(size_average=True)
+    m2 = FFNO2D(1, 1, width=16, n_layers=2, n_modes=7, factor=2, n_ff_layers=2, layer_norm=True).to(gpu_device).train()
+    m1 = FNO1d(1, 1, modes=9, width=8).to(gpu_device).train()
+    warm_plans(m2, [44, 88], 2, device=gpu_device)
+    warm_plans(m1, [200], 1, device=gpu_device)
+    assert m2.training and m1.training
+    n0 = lib.rpde_plan_cache_count()
+    for r in (44, 88):
+        x = torch.randn(2, 1, r, r, device=gpu_device)
+        loss_fn(m2(x), torch.randn_like(x)).backward()
+    x = torch.randn(3, 1, 200, device=gpu_device)
+    loss_fn(m1(x), torch.randn_like(x)).backward()
+    assert lib.rpde_plan_cache_count() == n0
+    m2(torch.randn(1, 1, 52, 52, device=gpu_device))
+    assert lib.rpde_plan_cache_count() > n0
