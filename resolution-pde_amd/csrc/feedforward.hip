@@ -11,6 +11,7 @@
 #include "pointwise.h"
 #include "gemm_kernel.h"
 #include "ff_fused.h"
+#include "wgrad_h2.h"
 
 namespace rpde {
 
@@ -60,7 +61,9 @@ static int linear_fwd_impl(const float* x, const float* w, const float* b, float
 // gw[out,in] = gy[P,out]^T . act_in(x)[P,in]   (split over P, slabs reduced here);  gb = colsum(gy)
 static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, long P, int in_f, int out_f,
                              float* ws_slabs, float* ws_colsum, hipStream_t st) {
-  if (gw) {
+  if (gw && wgrad_h2_ok(P, out_f, in_f)) {
+    RPDE_TRY(wgrad_h2(gy, x, gw, P, in_f, out_f, RPDE_ACT_IDENTITY, ws_slabs, st));
+  } else if (gw) {
     const int S = wgrad_split(P, out_f, in_f);
     rpde_gemm_desc d = gemm_desc();
     d.A = gy; d.a_kmajor = 0; d.lda = out_f;
@@ -112,7 +115,8 @@ static size_t ff_wimg_floats(int hid) { return (split_bytes(hid, ((hid + 31) / 3
 
 static size_t wgrad_ws_floats(long P, int in_f, int out_f) {
   const int S = wgrad_split(P, out_f, in_f);
-  return (S > 1 ? (size_t)S * out_f * in_f : 0);
+  const size_t a = (S > 1 ? (size_t)S * out_f * in_f : 0), b = wgrad_h2_slab_floats(P, out_f, in_f);
+  return a > b ? a : b;
 }
 
 }  // namespace rpde

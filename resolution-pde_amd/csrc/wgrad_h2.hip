@@ -1,0 +1,231 @@
+// Weight gradient of a pointwise linear layer, gW[out, in] = sum_p gy[p, out] * h[p, in], for the FeedForward of the
+// headline configuration (reference: autograd of models/custom_layer.py:58 nn.Linear inside FeedForward): a product
+// whose reduction runs over the P = B*M*N grid points (2.1 M at B = 32, 256^2) and whose output is tiny.  It streams
+// both operands exactly once, so it is HBM bound as soon as the matrix work fits under the stream -- which the
+// generic six-term bf16 split (gemm_bf16x3.hip, 1.59 ms for 4.3 GB at 256x256) does not achieve and the three-term f16
+// split of h2.h does.
+//
+// One workgroup of eight waves owns the whole [out x in] output (up to 256 x 256: 128 accumulator registers per lane)
+// and one contiguous chunk of the points, so every operand byte is read from HBM exactly once; 256 workgroups fill
+// the chip once, the per-chunk results go to slabs that reduce_slabs folds in fixed order (no float atomics:
+// run-to-run identical).  (A first version gave 128 output rows to each of two workgroups per chunk: the second
+// read of the other operand did not stay in L2 and the kernel ran at the HBM roof of 1.5x the bytes, 1.25 ms instead
+// of 0.9 ms at 256 x 256.)
+//
+// Per step of 32 points: the operands arrive as [32 points][64 channels] fp32 panels (256-byte rows: coalesced), one
+// panel per loader wave, which finds the panel's maximum (DPP wave reduction), scales by a power of two, splits into
+// hi / lo f16 pieces and stores them in memory order; both MFMA operands are then fetched with the transposing LDS
+// read (ds_read_b64_tr_b16: the reduction index, the point, becomes the fragment's k).  Double-buffered LDS stages,
+// one barrier per step, global loads one step ahead in registers.
+//
+// Scaling.  f16 pieces need the data near 2^14; a sum over two million points is dominated by its largest terms, so
+// precision relative to the largest magnitude seen so far is what the result needs.  Each panel column block keeps a
+// RUNNING exponent (the maximum over the steps so far, owned by its loader wave and published per stage); operands
+// are scaled by it, and a consumer wave whose panels' exponents moved rescales its accumulators once (a wave-uniform
+// branch that is taken a handful of times per launch).  No pass over the data to find a global maximum, no
+// per-step accumulator arithmetic, robust to isolated huge points.
+#include "h2.h"
+#include "pointwise.h"
+#include "wgrad_h2.h"
+
+#include <stdlib.h>
+
+namespace rpde {
+
+constexpr int WG_WAVES = 8;
+constexpr int WG_PANEL = 8192;                 // bytes per panel stage: [hi | lo][32 points][64 channels] f16
+constexpr int WG_BLOCKS = 256;                 // one workgroup per CU
+
+// byte offset of 8-byte chunk c8 (channels 4 c8 .. 4 c8 + 3) of point-row k in one piece of a panel (128-byte rows);
+// XOR swizzle so that the transposing reads (rows 8g+q and 8g+4+q per 16-lane group) cover all banks
+__device__ __forceinline__ int wg_off(int k, int c8) {
+  return k * 128 + ((c8 ^ ((((k >> 1) & 1) << 2) | (((k >> 3) & 1) << 3))) << 3);
+}
+
+// LDS traffic done + workgroup barrier, without waiting for outstanding global loads (as __syncthreads() would)
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct WgP {
+  const float* a;      // gy  [P, M]
+  const float* b;      // h   [P, N]
+  float* slabs;        // [nchunk][M][N]
+  long npts;           // P
+  long steps;          // ceil(P / 32): rows past P read as zeros
+  int M, N, nchunk;
+};
+
+// PA / PB: 64-channel panels of the A block / of B; waves WM x WN, each TM x TN tiles of 16 x 16; ACT: B = gelu(b)
+template <int PA, int PB, int WM, int WN, int TM, int TN, bool ACT>
+__global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
+  static_assert(WM * WN == WG_WAVES && PA + PB <= WG_WAVES, "eight waves, one panel per loader wave");
+  static_assert(WM * TM * 16 == PA * 64 && WN * TN * 16 == PB * 64, "wave tiles cover the block");
+  static_assert((TM * 16) % 64 == 0 || 64 % (TM * 16) == 0, "a wave tile stays inside one panel or covers whole panels");
+  constexpr int STAGE = (PA + PB) * WG_PANEL;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ int einfo[2][WG_WAVES];
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, g = l >> 4, li = l & 15;
+  const int chunk = blockIdx.x, mblock = blockIdx.y;
+  const long s0 = P.steps * chunk / P.nchunk, s1 = P.steps * (chunk + 1) / P.nchunk;
+
+  // ---- loader role: wave w < PA + PB owns panel w ----------------------------------------------------------------
+  const bool loader = wave < PA + PB, isA = wave < PA;
+  const int ld = isA ? P.M : P.N;
+  const float* __restrict__ src = isA ? P.a + mblock * (64 * PA) + 64 * wave : P.b + 64 * (wave - PA);
+  src += (long)g * ld + 4 * li;                       // this lane: rows g, g+4, .., g+28 of a step, channels 4 li ..
+  float4 buf[8];
+  int e_run = 15;
+  auto issue = [&](long s) {
+    if (!loader || s >= s1) return;
+    const float* __restrict__ q0 = src + s * 32 * ld;
+    if ((s + 1) * 32 <= P.npts) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) buf[i] = *reinterpret_cast<const float4*>(q0 + (long)(4 * i) * ld);
+    } else {                                          // the last, partial step
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        buf[i] = s * 32 + 4 * i + g < P.npts ? *reinterpret_cast<const float4*>(q0 + (long)(4 * i) * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto convert = [&](int st) {
+    if (!loader) return;
+    if (ACT && !isA) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { buf[i].x = gelu_f(buf[i].x); buf[i].y = gelu_f(buf[i].y); buf[i].z = gelu_f(buf[i].z); buf[i].w = gelu_f(buf[i].w); }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = fmaxf(fmaxf(m, fmaxf(fabsf(buf[i].x), fabsf(buf[i].y))), fmaxf(fabsf(buf[i].z), fabsf(buf[i].w)));
+    m = wave_max(m);
+    e_run = max(e_run, (int)(__float_as_uint(m) >> 23) & 0xff);
+    e_run = min(e_run, 254);
+    const float scale = __uint_as_float((unsigned)(268 - e_run) << 23);        // running maximum -> [2^14, 2^15)
+    char* const dst = smem + st * STAGE + wave * WG_PANEL;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint2 hi, lo;
+      h2_split4(buf[i].x * scale, buf[i].y * scale, buf[i].z * scale, buf[i].w * scale, hi, lo);
+      const int off = wg_off(4 * i + g, li);
+      *reinterpret_cast<uint2*>(dst + off) = hi;
+      *reinterpret_cast<uint2*>(dst + 4096 + off) = lo;
+    }
+    if (l == 0) einfo[st][wave] = e_run;
+  };
+
+  // ---- consumer role ---------------------------------------------------------------------------------------------
+  const int wm = wave / WN, wn = wave % WN;
+  const int m_off = wm * TM * 16, n_off = wn * TN * 16;            // inside the block
+  const int pa = m_off >> 6, ta0 = (m_off & 63) >> 4, pb = PA + (n_off >> 6), tb0 = (n_off & 63) >> 4;
+  // transposing-read address of this lane inside a piece: rows 8g+q (and +4), chunk pp of the tile
+  const int q = li >> 2, pp = li & 3;
+  const int tsw = ((q >> 1) & 1) | ((g & 1) << 1);
+  const int trow = (8 * g + q) * 128 + pp * 8;
+  typedef s16x4v __attribute__((address_space(3))) * lds_tr;
+  auto frag = [&](const char* panel, int tile, f16x8& hi, f16x8& lo) {
+    const char* t = panel + trow + ((tile ^ tsw) << 5);
+    union { struct { s16x4v a, b; } h; f16x8 v; } uh, ul;
+    uh.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t));
+    uh.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 512));
+    ul.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 4096));
+    ul.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 4096 + 512));
+    hi = uh.v; lo = ul.v;
+  };
+  f32x4v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  constexpr int NPA = (TM * 16 + 63) / 64;     // A panels under this wave's tile (each has its own running exponent)
+  static_assert(TN * 16 <= 64, "one B panel per wave tile");
+  int ea_used[NPA], eb_used = 15;              // exponents the accumulators are expressed in
+#pragma unroll
+  for (int k = 0; k < NPA; ++k) ea_used[k] = 15;
+
+  if (s0 < s1) {
+    issue(s0);
+    convert(0);
+    issue(s0 + 1);
+    wg_barrier();                            // the stage is written; global loads stay in flight
+    for (long s = s0; s < s1; ++s) {
+      const int cur = (int)(s - s0) & 1;
+      const char* const stage = smem + cur * STAGE;
+      const int eb = __builtin_amdgcn_readfirstlane(einfo[cur][pb]);
+#pragma unroll
+      for (int k = 0; k < NPA; ++k) {
+        const int ea = __builtin_amdgcn_readfirstlane(einfo[cur][pa + k]);
+        if (ea + eb != ea_used[k] + eb_used) {                               // rare: a new running maximum
+          const int d = (ea_used[k] + eb_used) - (ea + eb);                  // < 0
+          const float f = d > -126 ? __uint_as_float((unsigned)(127 + d) << 23) : 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            if (((ta0 + i) >> 2) == k) {
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] *= f;
+            }
+        }
+        ea_used[k] = ea;
+      }
+      eb_used = eb;
+      f16x8 bh[TN], bl[TN];                   // B fragments stay, A fragments stream: TN <= 4 in every instance
+#pragma unroll
+      for (int j = 0; j < TN; ++j) frag(stage + (pb + ((tb0 + j) >> 2)) * WG_PANEL, (tb0 + j) & 3, bh[j], bl[j]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        f16x8 ah, al;
+        frag(stage + (pa + ((ta0 + i) >> 2)) * WG_PANEL, (ta0 + i) & 3, ah, al);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = h2_mfma32(ah, al, bh[j], bl[j], acc[i][j]);
+      }
+      if (s + 1 < s1) {
+        convert(cur ^ 1);                    // waits for the loads of step s + 1
+        issue(s + 2);
+      }
+      wg_barrier();
+    }
+  }
+
+  // ---- slab [M][N] of this chunk ------------------------------------------------------------------------------------
+  const float fb = __uint_as_float((unsigned)(eb_used - 14) << 23);
+  float* __restrict__ out = P.slabs + (long)chunk * P.M * P.N + (long)(mblock * (64 * PA) + m_off) * P.N + n_off;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const float fa = __uint_as_float((unsigned)(ea_used[(ta0 + i) >> 2] - 14) << 23);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(long)(16 * i + 4 * g + r) * P.N + 16 * j + li] = acc[i][j][r] * fa * fb;
+  }
+}
+
+bool wgrad_h2_ok(long P, int out_f, int in_f) {
+  const char* e = getenv("RPDE_WGRAD_H2");
+  if ((e && e[0] == '0') || P < 32L * WG_BLOCKS) return false;
+  return (out_f == 256 && in_f == 256) || (out_f == 256 && in_f == 64) || (out_f == 64 && in_f == 256);
+}
+
+static int wg_chunks(int, int) { return WG_BLOCKS; }
+
+size_t wgrad_h2_slab_floats(long P, int out_f, int in_f) {
+  return wgrad_h2_ok(P, out_f, in_f) ? (size_t)wg_chunks(out_f, in_f) * out_f * in_f : 0;
+}
+
+template <int PA, int PB, int WM, int WN, int TM, int TN>
+static void wg_launch(const WgP& p, int mblocks, bool act, hipStream_t st) {
+  const dim3 grid(p.nchunk, mblocks);
+  if (act) hipLaunchKernelGGL((k_wgrad_h2<PA, PB, WM, WN, TM, TN, true>), grid, dim3(64 * WG_WAVES), 0, st, p);
+  else hipLaunchKernelGGL((k_wgrad_h2<PA, PB, WM, WN, TM, TN, false>), grid, dim3(64 * WG_WAVES), 0, st, p);
+}
+
+int wgrad_h2(const float* gy, const float* h, float* gw, long P, int in_f, int out_f, int act_b, float* slabs, hipStream_t st) {
+  RPDE_CHECK_ARG(wgrad_h2_ok(P, out_f, in_f) && slabs, "wgrad_h2: unsupported shape");
+  RPDE_CHECK_ARG(act_b == RPDE_ACT_IDENTITY || act_b == RPDE_ACT_GELU, "wgrad_h2: activation %d", act_b);
+  WgP p;
+  p.a = gy; p.b = h; p.slabs = slabs; p.npts = P; p.steps = (P + 31) / 32; p.M = out_f; p.N = in_f; p.nchunk = wg_chunks(out_f, in_f);
+  const bool act = act_b == RPDE_ACT_GELU;
+  if (out_f == 256 && in_f == 256) wg_launch<4, 4, 2, 4, 8, 4>(p, 1, act, st);
+  else if (out_f == 256) wg_launch<4, 1, 4, 2, 4, 2>(p, 1, act, st);
+  else wg_launch<1, 4, 1, 8, 4, 2>(p, 1, act, st);
+  RPDE_LAUNCH_CHECK();
+  return reduce_slabs(slabs, gw, (long)out_f * in_f, p.nchunk, (long)out_f * in_f, 1.f, 0, st);
+}
+
+}  // namespace rpde

@@ -188,3 +188,36 @@ def test_fno2d_evaluation_path_equals_training_path_forward(gpu_device):
     with torch.no_grad():
         e1 = m1(x1)
     assert _rel(e1, m1(x1.requires_grad_(True)).detach()) < 2e-6
+
+
+@pytest.mark.parametrize("in_f,out_f", [(256, 256), (64, 256), (256, 64)])
+@pytest.mark.parametrize("P", [32 * 640, 32 * 811 + 7])
+def test_streaming_weight_gradient_kernel(gpu_device, in_f, out_f, P):
+    """csrc/wgrad_h2.hip (running-exponent f16 pieces, transposing LDS reads) against float64 and against the generic
+    split-bf16 GEMM it replaces for the headline FeedForward shapes; rows whose magnitudes differ by 1e9 and a step
+    in which the running maximum jumps exercise the accumulator rescaling"""
+    from rpde import ops
+    torch.manual_seed(in_f + out_f + P)
+    x = torch.randn(P, in_f, device=gpu_device)
+    g = torch.randn(P, out_f, device=gpu_device)
+    x[::7] *= 1e-4
+    g[::5] *= 1e-5
+    x[P // 2: P // 2 + 3] *= 3e4                       # late, isolated huge rows: the running exponents move mid-stream
+    g[3 * P // 4] *= 1e5
+    w = torch.randn(out_f, in_f, device=gpu_device) / in_f ** 0.5
+    b = torch.zeros(out_f, device=gpu_device)
+
+    def grads():
+        ws, bs = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ops.linear(x, ws, bs).backward(g)
+        return ws.grad, bs.grad
+    gw, gb = grads()
+    gw2, _ = grads()
+    assert torch.equal(gw, gw2)                                                # fixed-order slabs: reproducible
+    with _env(RPDE_WGRAD_H2="0"):
+        gw_gemm, _ = grads()
+    ref = g.double().t() @ x.double()
+    assert _rel(gw, ref) < 2e-6, _rel(gw, ref)
+    assert _rel(gw_gemm, ref) < 2e-6
+    assert not torch.equal(gw, gw_gemm)                                        # really two different kernels
+    assert _rel(gb, g.double().sum(0)) < 2e-6
