@@ -89,7 +89,7 @@ def time_feedforward(B, device, iters=10):
       fwd_eval   the same call without hidden buffers (k_ff3_fwd_h2<false>: nothing but the output is written)
       bwd_chain  rpde_feedforward_bwd with every gradient pointer NULL except nothing: preparation + k_ff3_bwd_h2
                  (LayerNorm / dropout adjoint and the data-gradient chain; writes dz3, du2, du1)
-      wgrad      the 256 x 256 weight-gradient GEMM (split-bf16, transposing LDS reads, 192 K-slabs)
+      wgrad      the 256 x 256 weight gradient (k_wgrad_h2: both operands streamed once, + the slab reduction)
     algorithmic bytes: every tensor that has to cross HBM once, 4 B per element"""
     from rpde import _lib
     lib = _lib.load()
@@ -133,15 +133,15 @@ def time_feedforward(B, device, iters=10):
     t_ft = _ev_time(fwd_train, iters)
     t_fe = _ev_time(fwd_eval, iters)
     t_bc = _ev_time(bwd_chain, iters)
-    # the 256 x 256 weight gradient, as rpde_feedforward_bwd launches it
-    d = _lib.GemmDesc()
-    d.batch, d.zdiv, d.alpha = 1, 1, 1.0
-    S = 192
-    slabs = torch.empty(S * hid * hid, device=device)
-    d.A, d.B, d.C = ds[1].data_ptr(), hs[0].data_ptr(), slabs.data_ptr()
-    d.M, d.N, d.K, d.a_kmajor, d.b_kmajor = hid, hid, P, 0, 0
-    d.lda, d.ldb, d.ldc, d.ksplit, d.sCk = hid, hid, hid, S, hid * hid
-    t_wg = _time_gemm(d, max(5, iters // 2))
+    # the 256 x 256 weight gradient, as rpde_feedforward_bwd launches it: k_wgrad_h2 + the fixed-order slab reduction
+    gw = torch.empty(hid, hid, device=device)
+    nlw = lib.rpde_linear_ws_bytes(P, hid, hid)
+    wsl = _lib.workspace(nlw, device)
+
+    def wgrad():
+        _lib.check(lib.rpde_linear_bwd(hs[0].data_ptr(), ws_[1].data_ptr(), ds[1].data_ptr(), None, gw.data_ptr(), None, P, hid, hid,
+                                       wsl.data_ptr(), nlw, st), "linear bwd (weight gradient)")
+    t_wg = _ev_time(wgrad, iters)
     flops_fwd = 2.0 * P * (dim * hid + hid * hid + hid * dim)
     by_train = 4.0 * P * (4 * dim + 4 * hid)            # x, residual, out, z3 + h1, d1, h2, d2
     by_eval = 4.0 * P * 3 * dim                         # x, residual, out
@@ -418,12 +418,8 @@ def main():
                     ff["fwd_eval_ms"], fp32_equiv_tflops=tf(ff["flops_fwd"], ff["fwd_eval_ms"])),
                 hbm("k_ff3_bwd_h2: LayerNorm/dropout adjoint + data-gradient chain (reads g, z3, d2, d1; writes dz3, du2, du1)",
                     ff["bytes_chain"], ff["bwd_chain_ms"]),
-                {"kernel": "gemm split-bf16 TN weight gradient [256,P]x[P,256] (transposing LDS reads), split-K 192 slabs",
-                 "bound": "mfma", "achieved": tf(ff["flops_wgrad"], ff["wgrad_ms"]), "peak": round(PEAK_BF16_MFMA_TF / 6, 1),
-                 "unit": "TFLOP/s (fp32-equivalent: 6 bf16 MFMA flops per fp32 flop)",
-                 "frac": round(tf(ff["flops_wgrad"], ff["wgrad_ms"]) / (PEAK_BF16_MFMA_TF / 6), 4),
-                 "ms_per_launch": round(ff["wgrad_ms"], 4),
-                 "hbm_gbs": round(ff["bytes_wgrad"] / (ff["wgrad_ms"] * 1e-3) / 1e9, 1)},
+                hbm("k_wgrad_h2 + reduce_slabs: weight gradient [256,P]x[P,256] (reads du2 and h1 once; 256 slabs of 256 KB)",
+                    ff["bytes_wgrad"], ff["wgrad_ms"], fp32_equiv_tflops=tf(ff["flops_wgrad"], ff["wgrad_ms"])),
                 hbm("FSpectralConv2d backward (adjoint analysis, mode mix^T + weight gradients, adjoint synthesis + skip)",
                     2 * s_bytes, s_bwd_ms),
                 hbm("BASELINE config 5: SpectralConv2d(32,32,12,12) forward at [8,32,512,512] (k_cf_analysis_h2, row DFT, "

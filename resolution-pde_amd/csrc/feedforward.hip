@@ -224,11 +224,14 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
     if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
     int grid = 0;
     RPDE_TRY(ff3_fused_bwd_launch(p, ds, z_last, grad_out, dz3, buf0, buf1, nullptr, part, &grid, P, fimg, st));
-    if (grad_x) RPDE_TRY(linear_dgrad_impl(buf1, p->weights[0], grad_x, P, p->dim, hid, nullptr, nullptr, st, wt));
+    // first layer: du1 feeds both the data gradient and the weight gradient -- one kernel reads it once for both
+    const bool both = grad_x && grad_weights && wgrad_h2_dgrad_ok(P, hid, p->dim);
+    if (grad_x && !both) RPDE_TRY(linear_dgrad_impl(buf1, p->weights[0], grad_x, P, p->dim, hid, nullptr, nullptr, st, wt));
     if (grad_weights) {
       RPDE_TRY(linear_wgrad_impl(hs[1], dz3, grad_weights[2], nullptr, P, hid, p->dim, slabs, small, st));
       RPDE_TRY(linear_wgrad_impl(hs[0], buf0, grad_weights[1], nullptr, P, hid, hid, slabs, small, st));
-      RPDE_TRY(linear_wgrad_impl(x, buf1, grad_weights[0], nullptr, P, p->dim, hid, slabs, small, st));
+      if (both) RPDE_TRY(wgrad_h2_dgrad(buf1, x, p->weights[0], grad_weights[0], grad_x, P, p->dim, hid, slabs, st));
+      else RPDE_TRY(linear_wgrad_impl(x, buf1, grad_weights[0], nullptr, P, p->dim, hid, slabs, small, st));
     }
     if (grad_biases) {
       RPDE_TRY(reduce_slabs(part, grad_biases[0], hid, grid, FF3_PART, 1.f, 0, st));

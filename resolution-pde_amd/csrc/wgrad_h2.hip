@@ -52,17 +52,26 @@ struct WgP {
   long npts;           // P
   long steps;          // ceil(P / 32): rows past P read as zeros
   int M, N, nchunk;
+  const float* w;      // DG only: the layer's weight [M, N]
+  float* gx;           // DG only: gx[P, N] = gy[P, M] . w
 };
 
-// PA / PB: 64-channel panels of the A block / of B; waves WM x WN, each TM x TN tiles of 16 x 16; ACT: B = gelu(b)
-template <int PA, int PB, int WM, int WN, int TM, int TN, bool ACT>
+// PA / PB: 64-channel panels of the A block / of B; waves WM x WN, each TM x TN tiles of 16 x 16; ACT: B = gelu(b).
+// DG: the layer's data gradient rides along -- gx[p, :] = gy[p, :] . W for the 32 points of every step, from the gy
+// panels that are in LDS anyway (plain 16-byte reads: here the reduction index is the channel), so gy is read from
+// HBM once for both gradients.  W (M x 64) sits in LDS as ready-made B fragments; each gy panel carries its own
+// scale, so a wave forms the partial product of one panel at a time and folds it in with that panel's factor.
+template <int PA, int PB, int WM, int WN, int TM, int TN, bool ACT, bool DG = false>
 __global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
+  static_assert(!DG || (PB == 1 && PA * 2 <= 8), "data gradient: N = 64, M <= 256");
+  constexpr int WFRAG = DG ? PA * 2 * 4 * 2048 : 0;      // [k-step][n-tile][hi | lo][64 lanes][16 B]
   static_assert(WM * WN == WG_WAVES && PA + PB <= WG_WAVES, "eight waves, one panel per loader wave");
   static_assert(WM * TM * 16 == PA * 64 && WN * TN * 16 == PB * 64, "wave tiles cover the block");
   static_assert((TM * 16) % 64 == 0 || 64 % (TM * 16) == 0, "a wave tile stays inside one panel or covers whole panels");
   constexpr int STAGE = (PA + PB) * WG_PANEL;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + WFRAG];
   __shared__ int einfo[2][WG_WAVES];
+  __shared__ float wmax[WG_WAVES];
   const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, g = l >> 4, li = l & 15;
   const int chunk = blockIdx.x, mblock = blockIdx.y;
   const long s0 = P.steps * chunk / P.nchunk, s1 = P.steps * (chunk + 1) / P.nchunk;
@@ -140,11 +149,49 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
 #pragma unroll
   for (int k = 0; k < NPA; ++k) ea_used[k] = 15;
 
+  // ---- DG: W as B fragments (k = output channel of the layer, n = input channel), one global power-of-two scale -----
+  char* const wfrag = smem + 2 * STAGE;
+  float w_inv = 1.f;
+  if (DG && s0 < s1) {
+    constexpr int NF = PA * 2 * 4 * 64 / (64 * WG_WAVES);     // (k-step, n-tile, lane) triples per thread
+    float wv[NF][8];
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < NF; ++r) {
+      const int c = tid + r * 64 * WG_WAVES, fl = c & 63, nt = (c >> 6) & 3, ks = c >> 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        wv[r][j] = P.w[(long)(32 * ks + 8 * (fl >> 4) + j) * P.N + 16 * nt + (fl & 15)];
+        m = fmaxf(m, fabsf(wv[r][j]));
+      }
+    }
+    m = wave_max(m);
+    if (l == 0) wmax[wave] = m;
+    __syncthreads();
+    m = 0.f;
+#pragma unroll
+    for (int i = 0; i < WG_WAVES; ++i) m = fmaxf(m, wmax[i]);
+    float w_scale;
+    h2_scale(m, 0, w_scale, w_inv);
+#pragma unroll
+    for (int r = 0; r < NF; ++r) {
+      const int c = tid + r * 64 * WG_WAVES, fl = c & 63, nt = (c >> 6) & 3, ks = c >> 8;
+      uint2 h0, l0, h1, l1;
+      h2_split4(wv[r][0] * w_scale, wv[r][1] * w_scale, wv[r][2] * w_scale, wv[r][3] * w_scale, h0, l0);
+      h2_split4(wv[r][4] * w_scale, wv[r][5] * w_scale, wv[r][6] * w_scale, wv[r][7] * w_scale, h1, l1);
+      char* d = wfrag + (ks * 4 + nt) * 2048 + fl * 16;
+      *reinterpret_cast<uint4*>(d) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+      *reinterpret_cast<uint4*>(d + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+  }
+  // this wave's output tile of gx: points 16 (wave & 1) .., input channels 16 (wave >> 1) ..
+  const int dg_mt = wave & 1, dg_nt = wave >> 1;
+
   if (s0 < s1) {
     issue(s0);
     convert(0);
     issue(s0 + 1);
-    wg_barrier();                            // the stage is written; global loads stay in flight
+    wg_barrier();                            // the stage (and the weight fragments) are written; global loads stay in flight
     for (long s = s0; s < s1; ++s) {
       const int cur = (int)(s - s0) & 1;
       const char* const stage = smem + cur * STAGE;
@@ -174,6 +221,30 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
         frag(stage + (pa + ((ta0 + i) >> 2)) * WG_PANEL, (ta0 + i) & 3, ah, al);
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = h2_mfma32(ah, al, bh[j], bl[j], acc[i][j]);
+      }
+      if (DG) {
+        f32x4v tot = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        const int row = 16 * dg_mt + li;                    // A fragment: lane = point, 8 consecutive channels
+#pragma unroll
+        for (int k = 0; k < PA; ++k) {
+          f32x4v part = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const char* pa_ = stage + k * WG_PANEL + wg_off(row, 2 * (4 * h + g));
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(pa_), al = *reinterpret_cast<const f16x8*>(pa_ + 4096);
+            const char* wb = wfrag + ((2 * k + h) * 4 + dg_nt) * 2048 + l * 16;
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(wb), bl = *reinterpret_cast<const f16x8*>(wb + 1024);
+            part = h2_mfma32(ah, al, bh, bl, part);
+          }
+          const int ek = __builtin_amdgcn_readfirstlane(einfo[cur][k]);
+          const float fk = __uint_as_float((unsigned)(ek - 14) << 23) * w_inv;
+          tot += part * fk;
+        }
+        const long p0 = s * 32 + 16 * dg_mt + 4 * g;
+        float* __restrict__ gq = P.gx + p0 * P.N + 16 * dg_nt + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (p0 + r < P.npts) gq[(long)r * P.N] = tot[r];
       }
       if (s + 1 < s1) {
         convert(cur ^ 1);                    // waits for the loads of step s + 1
@@ -215,11 +286,25 @@ static void wg_launch(const WgP& p, int mblocks, bool act, hipStream_t st) {
   else hipLaunchKernelGGL((k_wgrad_h2<PA, PB, WM, WN, TM, TN, false>), grid, dim3(64 * WG_WAVES), 0, st, p);
 }
 
+bool wgrad_h2_dgrad_ok(long P, int out_f, int in_f) { return wgrad_h2_ok(P, out_f, in_f) && out_f == 256 && in_f == 64; }
+
+int wgrad_h2_dgrad(const float* gy, const float* h, const float* w, float* gw, float* gx, long P, int in_f, int out_f,
+                   float* slabs, hipStream_t st) {
+  RPDE_CHECK_ARG(wgrad_h2_dgrad_ok(P, out_f, in_f) && slabs && w && gx, "wgrad_h2_dgrad: unsupported shape");
+  WgP p;
+  p.a = gy; p.b = h; p.slabs = slabs; p.npts = P; p.steps = (P + 31) / 32; p.M = out_f; p.N = in_f; p.nchunk = WG_BLOCKS;
+  p.w = w; p.gx = gx;
+  hipLaunchKernelGGL((k_wgrad_h2<4, 1, 4, 2, 4, 2, false, true>), dim3(p.nchunk, 1), dim3(64 * WG_WAVES), 0, st, p);
+  RPDE_LAUNCH_CHECK();
+  return reduce_slabs(slabs, gw, (long)out_f * in_f, p.nchunk, (long)out_f * in_f, 1.f, 0, st);
+}
+
 int wgrad_h2(const float* gy, const float* h, float* gw, long P, int in_f, int out_f, int act_b, float* slabs, hipStream_t st) {
   RPDE_CHECK_ARG(wgrad_h2_ok(P, out_f, in_f) && slabs, "wgrad_h2: unsupported shape");
   RPDE_CHECK_ARG(act_b == RPDE_ACT_IDENTITY || act_b == RPDE_ACT_GELU, "wgrad_h2: activation %d", act_b);
   WgP p;
   p.a = gy; p.b = h; p.slabs = slabs; p.npts = P; p.steps = (P + 31) / 32; p.M = out_f; p.N = in_f; p.nchunk = wg_chunks(out_f, in_f);
+  p.w = nullptr; p.gx = nullptr;
   const bool act = act_b == RPDE_ACT_GELU;
   if (out_f == 256 && in_f == 256) wg_launch<4, 4, 2, 4, 8, 4>(p, 1, act, st);
   else if (out_f == 256) wg_launch<4, 1, 4, 2, 4, 2>(p, 1, act, st);

@@ -100,7 +100,7 @@ def test_fused_feedforward_equals_gemm_path(gpu_device, scale, dropout):
     res = torch.randn(P, 64, device=gpu_device)
     g = torch.randn(P, 64, device=gpu_device)
     fused = _ff(ff, x, res, g, True)
-    with _env(RPDE_FUSED_FF="0"):
+    with _env(RPDE_FUSED_FF="0", RPDE_WGRAD_H2="0"):      # plain leg: per-layer GEMMs only
         plain = _ff(ff, x, res, g, True)
     names = ["out", "dx"] + [n for n, _ in ff.named_parameters()]
     for name, a, b in zip(names, fused, plain):
