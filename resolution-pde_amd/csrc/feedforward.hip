@@ -59,15 +59,16 @@ static int linear_fwd_impl(const float* x, const float* w, const float* b, float
 }
 
 // gw[out,in] = gy[P,out]^T . act_in(x)[P,in]   (split over P, slabs reduced here);  gb = colsum(gy)
+// act_x: the x operand is act_x(x) (recompute mode of the fused FeedForward: x holds u, the layer's input is gelu(u))
 static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, long P, int in_f, int out_f,
-                             float* ws_slabs, float* ws_colsum, hipStream_t st) {
+                             float* ws_slabs, float* ws_colsum, hipStream_t st, int act_x = RPDE_ACT_IDENTITY) {
   if (gw && wgrad_h2_ok(P, out_f, in_f)) {
-    RPDE_TRY(wgrad_h2(gy, x, gw, P, in_f, out_f, RPDE_ACT_IDENTITY, ws_slabs, st));
+    RPDE_TRY(wgrad_h2(gy, x, gw, P, in_f, out_f, act_x, ws_slabs, st));
   } else if (gw) {
     const int S = wgrad_split(P, out_f, in_f);
     rpde_gemm_desc d = gemm_desc();
     d.A = gy; d.a_kmajor = 0; d.lda = out_f;
-    d.B = x; d.b_kmajor = 0; d.ldb = in_f;
+    d.B = x; d.b_kmajor = 0; d.ldb = in_f; d.act_b = act_x;
     d.M = out_f; d.N = in_f; d.K = (int)P;
     if (S > 1) {
       d.C = ws_slabs; d.ldc = in_f; d.ksplit = S; d.sCk = (long)out_f * in_f;
@@ -215,7 +216,10 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   void* wt = ar.take(ff_wimg_floats(hid));
   if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
 
-  if (ff3_fused_ok(p, P) && hs && ds && hs[0] && hs[1] && ds[0] && ds[1]) {
+  if (ff3_fused_ok(p, P) && hs && hs[0] && hs[1]) {
+    // ds given: they hold d = gelu'(u) * dropscale and hs hold h.  ds absent: recompute mode, hs hold u = dropout(z)
+    const int recompute = !(ds && ds[0] && ds[1]);
+    const int act_h = recompute ? RPDE_ACT_GELU : RPDE_ACT_IDENTITY;
     // one fused kernel for the LayerNorm / dropout adjoint and the whole data-gradient chain; then the three
     // weight-gradient GEMMs on what it stored
     float* dz3 = ar.take((size_t)P * p->dim);
@@ -223,13 +227,14 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
     void* fimg = ar.take(ff3_fused_ws_floats());
     if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
     int grid = 0;
-    RPDE_TRY(ff3_fused_bwd_launch(p, ds, z_last, grad_out, dz3, buf0, buf1, nullptr, part, &grid, P, fimg, st));
+    RPDE_TRY(ff3_fused_bwd_launch(p, recompute ? hs : ds, recompute, z_last, grad_out, dz3, buf0, buf1, nullptr, part, &grid, P,
+                                  fimg, st));
     // first layer: du1 feeds both the data gradient and the weight gradient -- one kernel reads it once for both
     const bool both = grad_x && grad_weights && wgrad_h2_dgrad_ok(P, hid, p->dim);
     if (grad_x && !both) RPDE_TRY(linear_dgrad_impl(buf1, p->weights[0], grad_x, P, p->dim, hid, nullptr, nullptr, st, wt));
     if (grad_weights) {
-      RPDE_TRY(linear_wgrad_impl(hs[1], dz3, grad_weights[2], nullptr, P, hid, p->dim, slabs, small, st));
-      RPDE_TRY(linear_wgrad_impl(hs[0], buf0, grad_weights[1], nullptr, P, hid, hid, slabs, small, st));
+      RPDE_TRY(linear_wgrad_impl(hs[1], dz3, grad_weights[2], nullptr, P, hid, p->dim, slabs, small, st, act_h));
+      RPDE_TRY(linear_wgrad_impl(hs[0], buf0, grad_weights[1], nullptr, P, hid, hid, slabs, small, st, act_h));
       if (both) RPDE_TRY(wgrad_h2_dgrad(buf1, x, p->weights[0], grad_weights[0], grad_x, P, p->dim, hid, slabs, st));
       else RPDE_TRY(linear_wgrad_impl(x, buf1, grad_weights[0], nullptr, P, p->dim, hid, slabs, small, st));
     }

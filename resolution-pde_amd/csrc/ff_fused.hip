@@ -135,18 +135,25 @@ constexpr int FF_LDS = FF_INFO + 256;
 // store (the h / d tensors a training forward writes) several times per tile
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// bias, dropout, GELU on four consecutive features of one point; h and d = gelu'(u) * dropscale out
+// bias, dropout, GELU on four consecutive features of one point; u = dropout(z), h = gelu(u) and
+// d = gelu'(u) * dropscale out (whatever the caller does not use is dead code)
 __device__ __forceinline__ void ff_act4(const f32x4v acc, float inv, const float4 b, const DropCfg& drop, uint64_t id,
-                                        float (&h)[4], float (&d)[4]) {
+                                        float (&h)[4], float (&d)[4], float (&u)[4]) {
   float s[4] = {1.f, 1.f, 1.f, 1.f};
   if (drop.on()) drop_scale4(drop, id, s);
   const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float u = fmaf(acc[r], inv, bb[r]) * s[r];
-    act_both(RPDE_ACT_GELU, u, h[r], d[r]);
+    u[r] = fmaf(acc[r], inv, bb[r]) * s[r];
+    act_both(RPDE_ACT_GELU, u[r], h[r], d[r]);
     d[r] *= s[r];
   }
+}
+// the backward side of the recompute mode: d = gelu'(u) * dropscale from the stored u and the regenerated mask
+__device__ __forceinline__ float4 ff_dact4(const float4 u, const DropCfg& drop, uint64_t id) {
+  float s[4] = {1.f, 1.f, 1.f, 1.f};
+  if (drop.on()) drop_scale4(drop, id, s);
+  return make_float4(dgelu_f(u.x) * s[0], dgelu_f(u.y) * s[1], dgelu_f(u.z) * s[2], dgelu_f(u.w) * s[3]);
 }
 
 // eight scaled activations of a lane (two accumulator tiles) -> one B fragment (hi, lo) at dst / dst + 1 KB
@@ -158,8 +165,13 @@ __device__ __forceinline__ void ff_put_frag(char* dst, const float (&v)[8]) {
   *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
-template <bool TRAIN>
+// MODE 0: evaluation (only `out` is written); 1: training, h and d = gelu'(u) * dropscale of both hidden layers stored
+// (the per-GEMM backward's contract); 2: training, only u = dropout(z) stored (in the h buffers) -- the backward
+// kernel and the weight-gradient kernels re-evaluate gelu' / gelu while the data passes through them, which halves
+// this kernel's stores and the saved-for-backward footprint
+template <int MODE>
 __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
+  constexpr bool TRAIN = MODE != 0;
   __shared__ __attribute__((aligned(16))) char smem[FF_LDS];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, li = l & 15;
   // ---- W1, W2 slices -> registers; W3, biases, LayerNorm vectors -> LDS; once ----
@@ -298,13 +310,14 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
         acc = h2_mfma32(w1h[t][0], w1l[t][0], xh0, xl0, acc);
         acc = h2_mfma32(w1h[t][1], w1l[t][1], xh1, xl1, acc);
-        float h[4], d[4];
+        float h[4], d[4], u[4];
         const int hid = 16 * (2 * w + t) + 4 * g;
-        ff_act4(acc, inv1, *reinterpret_cast<const float4*>(vec + hid), A.drop[0], (uint64_t)(pt * 256 + hid), h, d);
-        if (TRAIN && pt < A.P) {
+        ff_act4(acc, inv1, *reinterpret_cast<const float4*>(vec + hid), A.drop[0], (uint64_t)(pt * 256 + hid), h, d, u);
+        if (MODE == 1 && pt < A.P) {
           *reinterpret_cast<float4*>(A.h1 + pt * 256 + hid) = make_float4(h[0], h[1], h[2], h[3]);
           *reinterpret_cast<float4*>(A.d1 + pt * 256 + hid) = make_float4(d[0], d[1], d[2], d[3]);
         }
+        if (MODE == 2 && pt < A.P) *reinterpret_cast<float4*>(A.h1 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[4 * t + r] = h[r] * sh1;
       }
@@ -337,10 +350,11 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
       float hv[8];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        float h[4], d[4];
+        float h[4], d[4], u[4];
         const int hid = 16 * (2 * w + t) + 4 * g;
-        ff_act4(acc[t], inv2, *reinterpret_cast<const float4*>(vec + 256 + hid), A.drop[1], (uint64_t)(pt * 256 + hid), h, d);
-        if (TRAIN && pt < A.P) {
+        ff_act4(acc[t], inv2, *reinterpret_cast<const float4*>(vec + 256 + hid), A.drop[1], (uint64_t)(pt * 256 + hid), h, d, u);
+        if (MODE == 2 && pt < A.P) *reinterpret_cast<float4*>(A.h2 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
+        if (MODE == 1 && pt < A.P) {
           *reinterpret_cast<float4*>(A.h2 + pt * 256 + hid) = make_float4(h[0], h[1], h[2], h[3]);
           *reinterpret_cast<float4*>(A.d2 + pt * 256 + hid) = make_float4(d[0], d[1], d[2], d[3]);
         }
@@ -363,9 +377,11 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
                        *reinterpret_cast<const f16x8*>(hb), *reinterpret_cast<const f16x8*>(hb + 1024), acc3);
     }
     if (w < 2 && next_tile < A.ntiles) {
-      // the DMA of the next input tile was issued before this tile's stores (16 when training): it is older than the
-      // eight youngest of them, so vmcnt(8) covers it without waiting for all stores to be acknowledged
-      if (TRAIN) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the DMA of the next input tile was issued before this tile's stores (16 in mode 1, 8 in mode 2): it is older
+      // than the youngest half of them, so a partial wait covers it without waiting for every store to be acknowledged
+      if (MODE == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (MODE == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       s_convert(par ^ 1);
     }
     float v[4];
@@ -496,6 +512,7 @@ struct FF3B {
   float* part;
   long P; int layer_norm; float eps; int post_act;
   DropCfg drop2;
+  DropCfg drop0, drop1;  // RECOMP only: masks of the hidden layers
   float dmax;            // bound of |gelu'| * dropout scale
   int ntiles;
 };
@@ -521,6 +538,9 @@ __device__ __forceinline__ float row_sum15(float v) {
   return v;
 }
 
+// RECOMP: A.d2 / A.d1 hold u = dropout(z) of the hidden layers (forward mode 2); the derivative factors are
+// re-evaluated here from u and the regenerated dropout masks
+template <bool RECOMP>
 __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
   __shared__ __attribute__((aligned(16))) char smem[FB_LDS];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, li = l & 15;
@@ -730,7 +750,8 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
         acc = h2_mfma32(w3h[t][0], w3l0, zh0, zl0, acc);
         acc = h2_mfma32(w3h[t][1], w3l1, zh1, zl1, acc);
         const int hid = 16 * (2 * w + t) + 4 * g;
-        const float4 d = *reinterpret_cast<const float4*>(smem + FB_D2 + (w * 4 + blk * 2 + t) * 1024 + l * 16);
+        float4 d = *reinterpret_cast<const float4*>(smem + FB_D2 + (w * 4 + blk * 2 + t) * 1024 + l * 16);
+        if (RECOMP) d = ff_dact4(d, A.drop1, (uint64_t)(pt * 256 + hid));
         const float u[4] = {acc[0] * inv_a * d.x, acc[1] * inv_a * d.y, acc[2] * inv_a * d.z, acc[3] * inv_a * d.w};
         if (pt < A.P) {
           *reinterpret_cast<float4*>(A.du2 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
@@ -783,7 +804,8 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int hid = 16 * (2 * w + t) + 4 * g;
-          const float4 d = *reinterpret_cast<const float4*>(smem + FB_D1 + (w * 4 + blk * 2 + t) * 1024 + l * 16);
+          float4 d = *reinterpret_cast<const float4*>(smem + FB_D1 + (w * 4 + blk * 2 + t) * 1024 + l * 16);
+          if (RECOMP) d = ff_dact4(d, A.drop0, (uint64_t)(pt * 256 + hid));
           const float u[4] = {acc[blk][t][0] * inv_b * d.x, acc[blk][t][1] * inv_b * d.y,
                               acc[blk][t][2] * inv_b * d.z, acc[blk][t][3] * inv_b * d.w};
           if (pt < A.P) {
@@ -839,9 +861,11 @@ int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual
   RPDE_LAUNCH_CHECK();
   FF3P A;
   memset(&A, 0, sizeof(A));
-  const bool train = hs && ds && hs[0] && hs[1] && ds[0] && ds[1];
+  const bool have_h = hs && hs[0] && hs[1], have_d = ds && ds[0] && ds[1];
+  const int mode = have_h ? (have_d ? 1 : 2) : 0;
   A.x = x; A.res = residual; A.out = out; A.z3 = z_last;
-  if (train) { A.h1 = hs[0]; A.d1 = ds[0]; A.h2 = hs[1]; A.d2 = ds[1]; }
+  if (mode) { A.h1 = hs[0]; A.h2 = hs[1]; }
+  if (mode == 1) { A.d1 = ds[0]; A.d2 = ds[1]; }
   A.wimg = img; A.consts = consts; A.b1 = b1; A.b2 = b2; A.b3 = b3; A.gamma = p->ln_gamma; A.beta = p->ln_beta;
   A.P = P; A.layer_norm = p->layer_norm; A.eps = p->ln_eps; A.post_act = p->post_act;
   for (int l = 0; l < 3; ++l) {
@@ -856,8 +880,9 @@ int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual
   RPDE_HIP(hipGetDevice(&dev));
   RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int grid = A.ntiles < cus ? A.ntiles : cus;
-  if (train) hipLaunchKernelGGL(k_ff3_fwd_h2<true>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
-  else hipLaunchKernelGGL(k_ff3_fwd_h2<false>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
+  if (mode == 1) hipLaunchKernelGGL(k_ff3_fwd_h2<1>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
+  else if (mode == 2) hipLaunchKernelGGL(k_ff3_fwd_h2<2>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
+  else hipLaunchKernelGGL(k_ff3_fwd_h2<0>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;
 }
@@ -865,9 +890,9 @@ int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual
 size_t ff3_fused_bwd_part_floats() { return (size_t)1024 * FFB_PART; }
 
 // prep + the fused kernel: dz3 [P,64], du2, du1 [P,256], dx [P,64] (may be null), part [grid][704]; returns the grid
-int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, const float* z_last, const float* grad_out,
-                         float* dz3, float* du2, float* du1, float* dx, float* part, int* grid_out, long P, void* ws,
-                         hipStream_t st) {
+int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, int recompute, const float* z_last,
+                         const float* grad_out, float* dz3, float* du2, float* du1, float* dx, float* part, int* grid_out,
+                         long P, void* ws, hipStream_t st) {
   char* img = static_cast<char*>(ws);
   float* consts = reinterpret_cast<float*>(img + FF_IMG_BYTES);
   hipLaunchKernelGGL(k_ff3_prep_bwd, dim3(1), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], img, consts);
@@ -878,12 +903,14 @@ int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, const 
   A.dz3 = dz3; A.du2 = du2; A.du1 = du1; A.dx = dx;
   A.wimg = img; A.consts = consts; A.gamma = p->ln_gamma; A.beta = p->ln_beta; A.part = part;
   A.P = P; A.layer_norm = p->layer_norm; A.eps = p->ln_eps; A.post_act = p->post_act;
-  {
-    uint64_t z = p->seed + 0x9E3779B97F4A7C15ull * (uint64_t)(2 + 1);
+  DropCfg dc[3];
+  for (int l = 0; l < 3; ++l) {            // the forward's (seed, layer) -> mask mapping
+    uint64_t z = p->seed + 0x9E3779B97F4A7C15ull * (uint64_t)(l + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    A.drop2 = make_drop(p->dropout_p, z ^ (z >> 31));
+    dc[l] = make_drop(p->dropout_p, z ^ (z >> 31));
   }
+  A.drop0 = dc[0]; A.drop1 = dc[1]; A.drop2 = dc[2];
   A.dmax = 1.13f * A.drop2.scale;          // |gelu'| <= 1.129, times the dropout scale folded into d
   A.ntiles = (int)((P + 31) / 32);
   int dev = 0, cus = 256;
@@ -891,7 +918,8 @@ int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, const 
   RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   if (cus > 1024) cus = 1024;
   const int grid = A.ntiles < cus ? A.ntiles : cus;
-  hipLaunchKernelGGL(k_ff3_bwd_h2, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
+  if (recompute) hipLaunchKernelGGL(k_ff3_bwd_h2<true>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
+  else hipLaunchKernelGGL(k_ff3_bwd_h2<false>, dim3(grid), dim3(64 * FF_WAVES), 0, st, A);
   RPDE_LAUNCH_CHECK();
   *grid_out = grid;
   return RPDE_OK;

@@ -7,6 +7,8 @@ librpde_hip.so.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
@@ -157,9 +159,16 @@ class _FeedForward(torch.autograd.Function):
         need_grad = grad_on and any(ctx.needs_input_grad)     # (grad mode is always off inside forward itself)
         hid = dim * factor
         # the fused kernel keeps the hidden activations on chip: in evaluation nothing but `out` is allocated
-        lean = (not need_grad) and bool(lib.rpde_feedforward_is_fused(dim, factor, L, P))
+        fused = bool(lib.rpde_feedforward_is_fused(dim, factor, L, P))
+        lean = (not need_grad) and fused
+        # RPDE_FF_STASH=u: training through the fused kernels saves only u = dropout(z) of the hidden layers (in `hs`) and
+        # the backward kernels re-evaluate gelu / gelu' from it -- half the saved-for-backward footprint, but measured
+        # slower on MI355X (the erf-class vector work costs more than the 2 KB per point it keeps out of HBM:
+        # DESIGN.md section 6).  Default: h and d = gelu'(u) * dropscale are stored once by the forward kernel.
+        recompute = need_grad and fused and os.environ.get("RPDE_FF_STASH", "hd") == "u"
         hs = [None if lean else torch.empty(P, hid, dtype=torch.float32, device=x.device) for _ in range(L - 1)]
-        ds = [torch.empty(P, hid, dtype=torch.float32, device=x.device) if need_grad else None for _ in range(L - 1)]
+        ds = [torch.empty(P, hid, dtype=torch.float32, device=x.device) if (need_grad and not recompute) else None
+              for _ in range(L - 1)]
         z_last = torch.empty(P, dim, dtype=torch.float32, device=x.device)
         out = torch.empty(P, dim, dtype=torch.float32, device=x.device)
         wa, ba, ha, da = ptr_array(ws_), ptr_array(bs_), ptr_array(hs or [None]), ptr_array(ds or [None])

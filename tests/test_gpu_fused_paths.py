@@ -99,15 +99,19 @@ def test_fused_feedforward_equals_gemm_path(gpu_device, scale, dropout):
     x[::5] *= 1e-5
     res = torch.randn(P, 64, device=gpu_device)
     g = torch.randn(P, 64, device=gpu_device)
-    fused = _ff(ff, x, res, g, True)
+    with _env(RPDE_FF_STASH="u"):                         # recompute mode: only u = dropout(z) is saved
+        fused = _ff(ff, x, res, g, True)
+    fused_hd = _ff(ff, x, res, g, True)                   # default: the forward kernel stores h and d
     with _env(RPDE_FUSED_FF="0", RPDE_WGRAD_H2="0"):      # plain leg: per-layer GEMMs only
         plain = _ff(ff, x, res, g, True)
     names = ["out", "dx"] + [n for n, _ in ff.named_parameters()]
-    for name, a, b in zip(names, fused, plain):
-        assert torch.isfinite(a).all(), name
+    for name, a, a2, b in zip(names, fused, fused_hd, plain):
+        assert torch.isfinite(a).all() and torch.isfinite(a2).all(), name
         # (weight gradients are sums over 25789 points whose inputs span nine orders of magnitude: two fp32-class
         #  evaluations of such a sum agree to a few 1e-6 .. 1e-5)
-        assert _rel(a, b) < (2e-6 if name == "out" else 3e-5), (name, _rel(a, b))
+        tol = 2e-6 if name == "out" else 3e-5
+        assert _rel(a, b) < tol and _rel(a2, b) < tol, (name, _rel(a, b), _rel(a2, b))
+    assert torch.equal(fused[0], fused_hd[0])             # the forward arithmetic does not depend on what is saved
     # evaluation: nothing but the output is written, same numbers as the training-mode kernel without dropout
     ff.eval()
     with torch.no_grad():
