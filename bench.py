@@ -5,17 +5,25 @@ synthetic fields (BASELINE.json configs[2]), one process per GPU.
     python bench.py --gpus N --steps K --warmup W [--batch B]
 
 A step = forward + relative-L2 loss + backward + gradient all-reduce (N>1) +
-AdamW on one batch of B samples per GPU, inputs resident in HBM.  Rank 0 prints
+AdamW on one batch of B samples per GPU, inputs resident in HBM.  With --gpus N
+and no WORLD_SIZE in the environment the script spawns its N ranks itself
+(rpde/launch.py); under torch.distributed.run it is one of them.  Rank 0 prints
 ONE JSON line.  It also carries
-  * roofline: the dominant kernel (the 256->256 FeedForward GEMM whose epilogue
-    stores gelu(dropout(z)) and its derivative) timed live with HIP events on
-    the launch stream: algorithmic bytes per launch / time against 8 TB/s (the
-    split-bf16 kernel makes it HBM bound), fp32-equivalent TFLOP/s beside it;
-    roofline_extra: the layer's backward-data and weight-gradient GEMMs;
-  * roofline_spectral: the FSpectralConv2d.forward_fourier pipeline, algorithmic
-    bytes (SURVEY 8d: 33.55 MB*B + 1.31 MB per layer forward) against 8 TB/s;
+  * roofline: the dominant kernel -- k_ff3_fwd_h2<1>, the fused FeedForward
+    64->256->256->64 forward of one layer in training mode (reads x and the
+    residual, writes out, z3 and the saved h1, d1, h2, d2) -- timed live with
+    HIP events on the launch stream: algorithmic bytes per launch / time
+    against 8 TB/s; roofline_extra: the same kernel in evaluation, the fused
+    backward chain, the streaming weight-gradient kernel, the spectral
+    backward and the BASELINE config-5 SpectralConv2d forward;
+  * roofline_spectral: the FSpectralConv2d.forward_fourier pipeline (fused h2
+    analysis / synthesis kernels), algorithmic bytes (33.55 MB*B +
+    1.31 MB per layer forward) against 8 TB/s;
+  * roofline_step: all kernels of a step, PMC bytes (profiles/traffic.json)
+    over this run's step time;
   * cpu_baseline: the CPU oracle's training step timed on the host cores
-    (rank 0, N=1 only, bounded sample);
+    (rank 0, N=1 only, bounded sample: batch 4, 2 warm-up + 5 timed steps,
+    and one single-thread step);
   * parity: forward rel-L2 of the HIP path vs the oracle on identical inputs.
 """
 from __future__ import annotations

@@ -36,7 +36,7 @@ def main(kf, kw, sf, sw, B, steps, out, source):
     blob = {"source": source,
             "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2 FETCH + WRITE) KiB "
                    "(gfx950: FETCH_SIZE counts half of wide streaming reads); median over the launches of a kernel"}
-    dom = [k for k in res if k.startswith("k_ff3_fwd_h2<true>")]
+    dom = [k for k in res if k.startswith("k_ff3_fwd_h2<1>")]
     if dom:
         blob["dominant_kernel"] = {f"B{B}": res[dom[0]]["hbm_bytes_per_launch"], "kernel": dom[0]}
     blob["per_kernel"] = {f"B{B}": res}

@@ -16,3 +16,4 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 print("feedforward", bench.time_feedforward(B, dev, iters=3))
 print("spectral", bench.time_spectral(B, dev, iters=2))
+print("cfg5", bench.time_cfg5(dev, iters=2))
