@@ -14,7 +14,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = "cuda:0"
 torch.manual_seed(0)
-ff = FeedForward(64, 4, n_layers=3, layer_norm=True, dropout=0.1).to(dev)
+ff = FeedForward(64, 4, n_layers=3, layer_norm=True, dropout=float(os.environ.get("FF_DROPOUT", "0.1"))).to(dev)
 x = torch.randn(B, 256, 256, 64, device=dev)
 res = torch.randn(B, 256, 256, 64, device=dev)
 
