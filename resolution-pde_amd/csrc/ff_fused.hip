@@ -40,11 +40,13 @@ constexpr int FF_WAVES = 8;
 constexpr int FF_FRAGS = 24;                 // per wave: W1 4, W2 16, W3 4
 constexpr int FF_IMG_BYTES = FF_WAVES * FF_FRAGS * 2048;
 constexpr int FF_NCONST = 16;
+constexpr int FF_PREP_BLOCKS = FF_WAVES * FF_FRAGS * 64 / 1024;      // 12: one fragment item per thread
 
 // reduction-slot -> hidden feature inside a 32-wide slice, for operands built from two accumulator tiles
 __device__ __forceinline__ int ff_perm(int g, int j) { return 16 * (j >> 2) + 4 * g + (j & 3); }
 
-// ---- weight preparation: one block; maxima first, then the fragments in per-wave register order ----
+// ---- weight preparation: FF_PREP_BLOCKS blocks; each finds the maxima (all of the 98 K weights: cheap, and no grid
+// ---- synchronisation needed), then builds its share of the fragments in per-wave register order ----
 __global__ __launch_bounds__(1024) void k_ff3_prep(const float* __restrict__ w1, const float* __restrict__ w2,
                                                    const float* __restrict__ w3, const float* __restrict__ b1,
                                                    const float* __restrict__ b2, char* __restrict__ img,
@@ -56,11 +58,13 @@ __global__ __launch_bounds__(1024) void k_ff3_prep(const float* __restrict__ w1,
   float m1 = 0.f, m2 = 0.f, m3 = 0.f, r1 = 0.f, r2 = 0.f, bm = 0.f;
   for (int i = tid; i < 256 * 64; i += 1024) { m1 = fmaxf(m1, fabsf(w1[i])); m3 = fmaxf(m3, fabsf(w3[i])); }
   for (int i = tid; i < 256 * 256; i += 1024) m2 = fmaxf(m2, fabsf(w2[i]));
+  for (int row = wv; row < 256; row += 16) {          // row L1 norms, one wave per row (coalesced)
+    float a = fabsf(w1[row * 64 + l]);
+    float b = (fabsf(w2[row * 256 + l]) + fabsf(w2[row * 256 + 64 + l])) + (fabsf(w2[row * 256 + 128 + l]) + fabsf(w2[row * 256 + 192 + l]));
+    r1 = fmaxf(r1, wave_sum(a));
+    r2 = fmaxf(r2, wave_sum(b));
+  }
   if (tid < 256) {
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < 64; ++k) a += fabsf(w1[tid * 64 + k]);
-    for (int k = 0; k < 256; ++k) b += fabsf(w2[tid * 256 + k]);
-    r1 = a; r2 = b;
     bm = fabsf(b1 ? b1[tid] : 0.f);
   } else if (tid < 512) {
     bm = fabsf(b2 ? b2[tid - 256] : 0.f);          // kept apart below: threads 256..511 carry |b2|
@@ -79,12 +83,12 @@ __global__ __launch_bounds__(1024) void k_ff3_prep(const float* __restrict__ w1,
   float sc[3], iv[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) h2_scale(fin[k], 0, sc[k], iv[k]);
-  if (tid == 0) {
+  if (tid == 0 && blockIdx.x == 0) {
     consts[0] = iv[0]; consts[1] = iv[1]; consts[2] = iv[2];
     consts[3] = fin[3]; consts[4] = fin[4]; consts[5] = fin[5]; consts[6] = fin_b2;
   }
   // fragments: (wave, frag, lane) -> eight entries, scaled and split
-  for (int it = tid; it < FF_WAVES * FF_FRAGS * 64; it += 1024) {
+  for (int it = blockIdx.x * 1024 + tid; it < FF_WAVES * FF_FRAGS * 64; it += gridDim.x * 1024) {
     const int ln = it & 63, f = (it >> 6) % FF_FRAGS, w = it / (64 * FF_FRAGS);
     const int g = ln >> 4, li = ln & 15;
     float x[8];
@@ -478,8 +482,8 @@ __global__ __launch_bounds__(1024) void k_ff3_prep_bwd(const float* __restrict__
   float sc[3], iv[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) h2_scale(fin[k], 0, sc[k], iv[k]);
-  if (tid == 0) { consts[0] = iv[0]; consts[1] = iv[1]; consts[2] = iv[2]; consts[3] = fin[3]; consts[4] = fin[4]; }
-  for (int it = tid; it < FF_WAVES * FF_FRAGS * 64; it += 1024) {
+  if (tid == 0 && blockIdx.x == 0) { consts[0] = iv[0]; consts[1] = iv[1]; consts[2] = iv[2]; consts[3] = fin[3]; consts[4] = fin[4]; }
+  for (int it = blockIdx.x * 1024 + tid; it < FF_WAVES * FF_FRAGS * 64; it += gridDim.x * 1024) {
     const int ln = it & 63, f = (it >> 6) % FF_FRAGS, w = it / (64 * FF_FRAGS);
     const int g = ln >> 4, li = ln & 15;
     float x[8];
@@ -859,7 +863,7 @@ int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual
   const float* b1 = p->biases ? p->biases[0] : nullptr;
   const float* b2 = p->biases ? p->biases[1] : nullptr;
   const float* b3 = p->biases ? p->biases[2] : nullptr;
-  hipLaunchKernelGGL(k_ff3_prep, dim3(1), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], b1, b2, img, consts);
+  hipLaunchKernelGGL(k_ff3_prep, dim3(FF_PREP_BLOCKS), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], b1, b2, img, consts);
   RPDE_LAUNCH_CHECK();
   FF3P A;
   memset(&A, 0, sizeof(A));
@@ -897,7 +901,7 @@ int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, int re
                          long P, void* ws, hipStream_t st) {
   char* img = static_cast<char*>(ws);
   float* consts = reinterpret_cast<float*>(img + FF_IMG_BYTES);
-  hipLaunchKernelGGL(k_ff3_prep_bwd, dim3(1), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], img, consts);
+  hipLaunchKernelGGL(k_ff3_prep_bwd, dim3(FF_PREP_BLOCKS), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], img, consts);
   RPDE_LAUNCH_CHECK();
   FF3B A;
   memset(&A, 0, sizeof(A));
