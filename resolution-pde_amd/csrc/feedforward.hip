@@ -12,6 +12,7 @@
 #include "gemm_kernel.h"
 #include "ff_fused.h"
 #include "wgrad_h2.h"
+#include "thin_linear.h"
 
 namespace rpde {
 
@@ -43,6 +44,11 @@ static inline bool worth_presplit(long P, int n, int k) { return P >= 1024 && k 
 static int linear_fwd_impl(const float* x, const float* w, const float* b, float* y, long P, int in_f, int out_f,
                            int act_out, float* dy, float drop_p, uint64_t drop_seed, hipStream_t st,
                            void* wimg = nullptr) {
+  if (act_out == RPDE_ACT_IDENTITY && !dy && drop_p == 0.f) {
+    // lifting / projection shapes: streaming kernels instead of degenerate GEMMs (thin_linear.hip)
+    if (in_f <= 4 && thin_linear_ok(in_f, out_f)) return thin_expand(x, w, in_f, 1, b, y, P, in_f, out_f, st);
+    if (out_f <= 4 && thin_linear_ok(out_f, in_f)) return thin_contract(x, w, in_f, 1, b, y, P, out_f, in_f, st);
+  }
   rpde_gemm_desc d = gemm_desc();
   d.A = x; d.a_kmajor = 1; d.lda = in_f;
   d.B = w; d.b_kmajor = 1; d.ldb = in_f;
@@ -62,6 +68,11 @@ static int linear_fwd_impl(const float* x, const float* w, const float* b, float
 // act_x: the x operand is act_x(x) (recompute mode of the fused FeedForward: x holds u, the layer's input is gelu(u))
 static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, long P, int in_f, int out_f,
                              float* ws_slabs, float* ws_colsum, hipStream_t st, int act_x = RPDE_ACT_IDENTITY) {
+  if (act_x == RPDE_ACT_IDENTITY && (gw || gb)) {
+    // one pass over both operands gives the weight gradient and the bias gradient of a lifting / projection layer
+    if (in_f <= 4 && thin_linear_ok(in_f, out_f)) return thin_outer(x, gy, gw, 1, gb, nullptr, P, in_f, out_f, ws_slabs, st);
+    if (out_f <= 4 && thin_linear_ok(out_f, in_f)) return thin_outer(gy, x, gw, 0, nullptr, gb, P, out_f, in_f, ws_slabs, st);
+  }
   if (gw && wgrad_h2_ok(P, out_f, in_f)) {
     RPDE_TRY(wgrad_h2(gy, x, gw, P, in_f, out_f, act_x, ws_slabs, st));
   } else if (gw) {
@@ -97,6 +108,10 @@ static inline bool can_fuse_colsum(const float* gy, const float* w, const float*
 // first, which is what lets this GEMM take the split-bf16 path at all
 static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f,
                              const float* dstored, float* colsum_slab, hipStream_t st, void* wimg = nullptr) {
+  if (!dstored && !colsum_slab) {
+    if (out_f <= 4 && thin_linear_ok(out_f, in_f)) return thin_expand(gy, w, 1, in_f, nullptr, gx, P, out_f, in_f, st);
+    if (in_f <= 4 && thin_linear_ok(in_f, out_f)) return thin_contract(gy, w, 1, in_f, nullptr, gx, P, in_f, out_f, st);
+  }
   rpde_gemm_desc d = gemm_desc();
   d.A = gy; d.a_kmajor = 1; d.lda = out_f;
   d.B = w; d.b_kmajor = 0; d.ldb = in_f;
@@ -116,8 +131,12 @@ static size_t ff_wimg_floats(int hid) { return (split_bytes(hid, ((hid + 31) / 3
 
 static size_t wgrad_ws_floats(long P, int in_f, int out_f) {
   const int S = wgrad_split(P, out_f, in_f);
-  const size_t a = (S > 1 ? (size_t)S * out_f * in_f : 0), b = wgrad_h2_slab_floats(P, out_f, in_f);
-  return a > b ? a : b;
+  size_t a = (S > 1 ? (size_t)S * out_f * in_f : 0);
+  const size_t b = wgrad_h2_slab_floats(P, out_f, in_f);
+  if (b > a) a = b;
+  if (in_f <= 4 && thin_linear_ok(in_f, out_f) && thin_outer_ws_floats(P, in_f, out_f) > a) a = thin_outer_ws_floats(P, in_f, out_f);
+  if (out_f <= 4 && thin_linear_ok(out_f, in_f) && thin_outer_ws_floats(P, out_f, in_f) > a) a = thin_outer_ws_floats(P, out_f, in_f);
+  return a;
 }
 
 }  // namespace rpde
