@@ -316,8 +316,9 @@ def main():
 
     torch.manual_seed(0)                       # identical initial weights on every rank
     model = FFNO2D(**CFG3).to(device).train()
+    from rpde.optim import FlatAdamW
     bucket = FlatGradBucket(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    opt = FlatAdamW(model.parameters(), lr=1e-3, bucket=bucket)      # torch.optim.AdamW's rule, one kernel per step
     loss_fn = RelativeL2Loss(size_average=True)
     B = args.batch
     x, y = synth_batch(B, RES, 1234 + rank, device)
@@ -405,7 +406,7 @@ def main():
             "config": {"workload": "FFNO2D(1,1,width=64,n_layers=4,n_modes=20,factor=4,ff_weight_norm,n_ff_layers=3,"
                                    "layer_norm,dropout=0.1) train step on [B,1,256,256] Gaussian random fields "
                                    "(BASELINE configs[2])",
-                       "batch_per_gpu": B, "global_batch": B * world, "grid": [RES, RES], "optimizer": "AdamW lr=1e-3",
+                       "batch_per_gpu": B, "global_batch": B * world, "grid": [RES, RES], "optimizer": "AdamW lr=1e-3 (rpde.optim.FlatAdamW: torch.optim.AdamW's rule, one kernel)",
                        "parallelism": f"dp{world}" if world > 1 else "single", "grad_bucket_bytes": bucket.nbytes,
                        "allreduce_ms_per_step": round(ar_ms, 4),
                        "step_ms_p10_p50_p90": [round(pct(0.1), 3), round(pct(0.5), 3), round(pct(0.9), 3)],

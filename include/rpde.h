@@ -278,6 +278,22 @@ int rpde_rel_l2_bwd(const float* x, const float* y, const float* stats,
                     const float* grad_loss, const float* grad_rel, float* grad_x,
                     int B, int64_t per, int size_average, void* stream);
 
+/* ---- optimizer step: torch.optim.AdamW as built at main_1d.py:144 / main_2d.py:173 (decoupled weight decay,
+ * bias-corrected moments, no amsgrad), one streaming kernel over flat fp32 buffers of n (multiple of 4) elements.
+ * The caller passes the step's scalars: 1 - lr*wd, 1 - b1, b2, 1 - b2, lr / (1 - b1^t), sqrt(1 - b2^t), eps. */
+int rpde_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
+                    float one_minus_lr_wd, float one_minus_b1, float b2, float one_minus_b2,
+                    float step_size, float bc2_sqrt, float eps, void* stream);
+/* the same with the step counter on the device (step_dev[0..2]: t, lr/(1-b1^t), sqrt(1-b2^t); t is incremented
+ * by the call): nothing step-dependent crosses the host, so the step can be captured in a hipGraph */
+int rpde_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                        float lr, float b1, float b2, float eps, float weight_decay,
+                        float* step_dev, void* stream);
+/* the update of rpde_adamw_step_dev without advancing the counter (a second buffer of the same optimizer step) */
+int rpde_adamw_apply_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                         float lr, float b1, float b2, float eps, float weight_decay,
+                         const float* step_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

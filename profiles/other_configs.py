@@ -13,7 +13,8 @@ from models.fno import FNO1d, FNO2d  # noqa: E402
 from utils.loss import RelativeL2Loss  # noqa: E402
 
 dev = torch.device("cuda", 0)
-FUSED = os.environ.get("RPDE_FUSED_ADAMW", "0") != "0"      # torch's single-kernel AdamW (same update rule)
+FLAT = os.environ.get("RPDE_FLAT_ADAMW", "1") != "0"        # rpde.optim.FlatAdamW (one kernel per step) or torch.optim.AdamW
+from rpde.optim import FlatAdamW  # noqa: E402
 
 
 def timed(fn, iters=30, warm=10):
@@ -28,11 +29,11 @@ def timed(fn, iters=30, warm=10):
 
 
 def train_step(model, x, y):
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=FUSED)
+    opt = FlatAdamW(model.parameters(), lr=1e-3) if FLAT else torch.optim.AdamW(model.parameters(), lr=1e-3)
     loss_fn = RelativeL2Loss(size_average=True)
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad(set_to_none=not FLAT)
         loss_fn(model(x), y).backward()
         opt.step()
     return step
@@ -40,7 +41,8 @@ def train_step(model, x, y):
 
 def graphed(model, x, y):
     from rpde.graph import GraphedTrainStep
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=FUSED)
+    opt = (FlatAdamW(model.parameters(), lr=1e-3, capturable=True) if FLAT
+           else torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True))
     step = GraphedTrainStep(model, RelativeL2Loss(size_average=True), opt, x, y)
     return lambda: step(x, y)
 

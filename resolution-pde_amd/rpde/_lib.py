@@ -112,6 +112,9 @@ _SIGNATURES = {
     "rpde_rel_l2_stats_elems": (_L, [_I]),
     "rpde_rel_l2_fwd": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _P]),
     "rpde_rel_l2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
+    "rpde_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "rpde_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),
+    "rpde_adamw_apply_dev": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

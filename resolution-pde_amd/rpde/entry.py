@@ -88,11 +88,13 @@ def run(dims: int, argv=None):
         warm_plans(model, seen, dims, in_channels=int(train_set[0][0].shape[0]), device=device)
 
     lr = float(args.training.learning_rate)
+    # torch.optim.AdamW's update rule and state_dict format, one kernel per step (rpde/optim.py)
+    from rpde.optim import FlatAdamW
     if dims == 2:     # reference main_2d.py:173-174
-        optimizer = optim.AdamW(model.parameters(), lr=lr)
+        optimizer = FlatAdamW(model.parameters(), lr=lr)
         scheduler = optim.lr_scheduler.StepLR(optimizer, step_size=30, gamma=0.5)
     else:             # reference main_1d.py:144-145
-        optimizer = optim.AdamW(model.parameters(), lr=lr, weight_decay=1e-4)
+        optimizer = FlatAdamW(model.parameters(), lr=lr, weight_decay=1e-4)
         scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=100, eta_min=1e-5)
 
     n_params = sum(p.numel() for p in model.parameters())

@@ -27,12 +27,22 @@ class FlatGradBucket:
         dev = self.params[0].device
         sizes = [p.numel() * (2 if p.is_complex() else 1) for p in self.params]
         padded = [(n + 3) // 4 * 4 for n in sizes]          # 16-byte aligned chunks (complex views need even offsets)
-        self.flat = torch.zeros(sum(padded), dtype=torch.float32, device=dev)
+        # layout: all real parameters first, then the complex ones, each group in parameter order.  (One buffer for
+        # the collective; rpde.optim.FlatAdamW mirrors the two regions in separate storages, because torch.save
+        # refuses float and complex views of one storage in a state_dict.)
+        order = [i for i, p in enumerate(self.params) if not p.is_complex()] + \
+                [i for i, p in enumerate(self.params) if p.is_complex()]
+        self.offsets: List[int] = [0] * len(self.params)
         off = 0
+        for i in order:
+            self.offsets[i] = off
+            off += padded[i]
+        self.n_real = sum(padded[i] for i, p in enumerate(self.params) if not p.is_complex())     # complex region: [n_real, end)
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self._views: List[torch.Tensor] = []
         self._touched = set()
-        for i, (p, n, step) in enumerate(zip(self.params, sizes, padded)):
-            chunk = self.flat[off:off + n]
+        for i, (p, n) in enumerate(zip(self.params, sizes)):
+            chunk = self.flat[self.offsets[i]:self.offsets[i] + n]
             if p.is_complex():
                 view = torch.view_as_complex(chunk.view(*p.shape, 2))
             else:
@@ -42,7 +52,6 @@ class FlatGradBucket:
             self._views.append(view)
             p.grad = view
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touched.add(i))
-            off += step
 
     @property
     def nbytes(self) -> int:

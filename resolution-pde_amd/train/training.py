@@ -43,7 +43,8 @@ def _mean_over_ranks(total: torch.Tensor, count: int) -> float:
 def train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=None, use_normalizer=False, time=1,
           model_type="ffno", epochs=100, device="cuda", log: Optional[Callable[[dict], None]] = None):
     loss_fn = RelativeL2Loss(size_average=True)
-    bucket = FlatGradBucket(model.parameters())
+    # rpde.optim.FlatAdamW brings its own bucket (its gradients, parameters and moments share one flat layout)
+    bucket = getattr(optimizer, "bucket", None) or FlatGradBucket(model.parameters())
     loss_history, val_loss_history = [], []
     for epoch in range(epochs):
         model.train()

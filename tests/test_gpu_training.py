@@ -359,3 +359,78 @@ def test_warm_plans_leaves_no_plan_to_build_inside_a_step(gpu_device):
     assert lib.rpde_plan_cache_count() == n0
     m2(torch.randn(1, 1, 52, 52, device=gpu_device))
     assert lib.rpde_plan_cache_count() > n0
+
+
+def test_flat_adamw_matches_torch_adamw(gpu_device):
+    """rpde.optim.FlatAdamW (one kernel over flat buffers) against torch.optim.AdamW on a model with complex and real
+    parameters, weight decay, a learning-rate change and a parameter that takes no part in some steps; state_dict
+    interchange in both directions; the capturable variant inside a hipGraph"""
+    import copy
+    from models.fno import FNO2d
+    from rpde.graph import GraphedTrainStep
+    from rpde.optim import FlatAdamW
+    from utils.loss import RelativeL2Loss
+    torch.manual_seed(3)
+    m_t = FNO2d(1, 1, modes1=4, modes2=3, width=8, n_blocks=2).to(gpu_device).train()
+    m_f = copy.deepcopy(m_t)
+    extra_t = torch.nn.Parameter(torch.randn(7, device=gpu_device))           # used only in odd steps
+    extra_f = torch.nn.Parameter(extra_t.detach().clone())
+    o_t = torch.optim.AdamW(list(m_t.parameters()) + [extra_t], lr=2e-3, weight_decay=0.05)
+    o_f = FlatAdamW(list(m_f.parameters()) + [extra_f], lr=2e-3, weight_decay=0.05)
+    loss_fn = RelativeL2Loss(size_average=True)
+    x = torch.randn(3, 1, 16, 20, device=gpu_device)
+    y = torch.randn(3, 1, 16, 20, device=gpu_device)
+
+    def rel(a, b):
+        a = torch.view_as_real(a) if a.is_complex() else a
+        b = torch.view_as_real(b) if b.is_complex() else b
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+    for step in range(6):
+        if step == 3:
+            for o in (o_t, o_f):
+                o.param_groups[0]["lr"] = 5e-4
+        for model, opt, extra in ((m_t, o_t, extra_t), (m_f, o_f, extra_f)):
+            opt.zero_grad(set_to_none=True) if opt is o_t else opt.zero_grad()
+            loss = loss_fn(model(x), y)
+            if step % 2:
+                loss = loss + (extra * extra).sum() * 1e-2
+            loss.backward()
+            if opt is o_f:
+                opt.bucket.detach_untouched()
+            opt.step()
+    for (n, a), b in zip(m_f.named_parameters(), m_t.parameters()):
+        assert rel(a, b) < 2e-6, (n, rel(a, b))
+    assert rel(extra_f, extra_t) < 2e-6
+    sd_f, sd_t = o_f.state_dict(), o_t.state_dict()
+    assert [float(s["step"]) for s in sd_f["state"].values()] == [float(s["step"]) for s in sd_t["state"].values()]
+    assert float(list(sd_f["state"].values())[-1]["step"]) == 3.0            # the sometimes-unused parameter
+    for sf, st_ in zip(sd_f["state"].values(), sd_t["state"].values()):
+        assert rel(sf["exp_avg"], st_["exp_avg"]) < 1e-5 and rel(sf["exp_avg_sq"], st_["exp_avg_sq"]) < 1e-5
+    # checkpoints interchange: torch -> flat, continue, compare with torch continuing
+    o_f.load_state_dict(copy.deepcopy(sd_t))
+    with torch.no_grad():
+        for a, b in zip(list(m_f.parameters()) + [extra_f], list(m_t.parameters()) + [extra_t]):
+            a.copy_(b)
+    for model, opt in ((m_t, o_t), (m_f, o_f)):
+        opt.zero_grad()
+        loss_fn(model(x), y).backward()
+        if opt is o_f:
+            opt.bucket.detach_untouched()
+        opt.step()
+    for (n, a), b in zip(m_f.named_parameters(), m_t.parameters()):
+        assert rel(a, b) < 2e-6, (n, rel(a, b))
+    # capturable: the step counter lives on the device, the whole step replays as a graph
+    m_g, m_e = copy.deepcopy(m_t), copy.deepcopy(m_t)
+    o_g = FlatAdamW(m_g.parameters(), lr=1e-3, capturable=True)
+    o_e = torch.optim.AdamW(m_e.parameters(), lr=1e-3)
+    gstep = GraphedTrainStep(m_g, loss_fn, o_g, x, y, warmup=2)             # 2 warm-up + 1 captured (not replayed) step
+    for _ in range(3):
+        gstep(x, y)
+    for _ in range(2 + 3):
+        o_e.zero_grad()
+        loss_fn(m_e(x), y).backward()
+        o_e.step()
+    for (n, a), b in zip(m_g.named_parameters(), m_e.parameters()):
+        assert rel(a, b) < 5e-6, (n, rel(a, b))
+    assert float(next(iter(o_g.state_dict()["state"].values()))["step"]) == 5.0
