@@ -204,8 +204,9 @@ int thin_contract(const float* a, const float* w, long ws_t, long ws_o, const fl
   return RPDE_OK;
 }
 
+// at least 128 points per workgroup (a sweep of 256 threads covers 4 .. 64 of them), at most 1024 workgroups
 static int tl_outer_blocks(long P) {
-  long nb = (P + 1023) / 1024;
+  long nb = (P + 127) / 128;
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return (int)nb;
