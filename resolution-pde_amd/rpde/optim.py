@@ -10,7 +10,7 @@ checkpoints interchange with the reference's optimizer.
 
 The gradient buffer is a ``rpde.parallel.FlatGradBucket`` (created here unless one is passed): ``zero_grad()`` is
 ``bucket.zero()``, the data-parallel exchange is ``bucket.all_reduce_mean()``.  A parameter whose ``.grad`` is
-None at ``step()`` (outside this step's graph; ``bucket.detach_untouched()``) is skipped exactly as torch skips it:
+None at ``step()`` (outside this step's graph) is skipped exactly as torch skips it:
 no moment update, no weight decay, its step count stands still.
 
 ``capturable=True`` keeps the step counter on the device (``rpde_adamw_step_dev``), which lets
@@ -78,6 +78,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 loss = closure()
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], float(g["eps"]), float(g["weight_decay"])
+        self.bucket.gather()                                    # gradients into the flat buffer (no-op when done)
         params = self.bucket.params
         lib, st = load(), stream_ptr()
         base_g = self.bucket.flat.data_ptr()
@@ -85,7 +86,7 @@ class FlatAdamW(torch.optim.Optimizer):
         for i, p in enumerate(params):
             if p.grad is None:
                 continue
-            if p.grad.data_ptr() != base_g + 4 * self._offsets[i]:     # someone replaced .grad: bring it into the bucket
+            if p.grad.data_ptr() != base_g + 4 * self._offsets[i]:     # .grad replaced after gather(): bring it in
                 self.bucket._views[i].copy_(p.grad)
             live.append(i)
         if self._step_dev is not None:

@@ -35,6 +35,7 @@ def _worker(rank, world, port, path):
     xs, ys = x[rank * 2:(rank + 1) * 2].to(dev), y[rank * 2:(rank + 1) * 2].to(dev)
     bucket.zero()
     RelativeL2Loss()(model(xs), ys).backward()
+    bucket.gather()
     flat_cpu = bucket.flat.cpu()                       # gloo reduces host tensors
     dist.all_reduce(flat_cpu)
     flat_cpu /= world
@@ -60,6 +61,7 @@ def test_two_ranks_on_one_gpu_reproduce_full_batch_gradients(gpu_device, tmp_pat
     y = advance(x, 2)
     bucket.zero()
     RelativeL2Loss()(model(x.to(gpu_device)), y.to(gpu_device)).backward()
+    bucket.gather()
     ref = bucket.flat.cpu()
     rel = float((got - ref).norm() / ref.norm())
     assert rel < 1e-5, rel

@@ -32,8 +32,8 @@ def _worker(rank, world, port, tmp):
     bucket.zero()
     loss = ((model(xs) - ys) ** 2).mean() + (cw.abs() ** 2).sum() * xs.mean()
     loss.backward()
+    bucket.all_reduce_mean()                                                  # gathers first, then reduces
     assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in params)   # grads are views into the bucket
-    bucket.all_reduce_mean()
     # single-process reference on the full batch (mean of the two local means)
     ref_model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 1))
     ref_model.load_state_dict(model.state_dict())
@@ -144,8 +144,12 @@ def test_untouched_parameters_keep_grad_none_and_reference_modules_stay_importab
         assert b.weight.grad is None and a.weight.grad is not None
         opt.step()
     assert torch.equal(b.weight, before)                          # no weight decay, no moments: as after zero_grad()
-    bucket.zero()
+    bucket.zero()                                                 # every grad None: backward assigns, gather() collects
+    assert all(p.grad is None for p in params)
+    (a(torch.ones(1, 3)).sum() + b(torch.ones(1, 3)).sum()).backward()
+    bucket.gather()
     assert b.weight.grad is not None and b.weight.grad.data_ptr() >= bucket.flat.data_ptr()
+    assert torch.equal(bucket.flat[bucket.offsets[2]:bucket.offsets[2] + 6].view(2, 3), torch.ones(2, 3))
     # drop-in route of INTEGRATION.md A.2: with this tree ahead of the reference root the shared package names are
     # namespace packages, so the reference's own modules (utils/naive_utils.py ...) still resolve
     import importlib.util
