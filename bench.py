@@ -305,6 +305,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
         torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
     device = torch.device("cuda", local)

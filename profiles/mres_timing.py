@@ -15,14 +15,15 @@ from utils.loss import RelativeL2Loss  # noqa: E402
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = FFNO2D(**bench.CFG3).to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+from rpde.optim import FlatAdamW  # noqa: E402
+opt = FlatAdamW(model.parameters(), lr=1e-3)
 loss_fn = RelativeL2Loss(size_average=True)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 for res in (64, 128, 256):
     x, y = bench.synth_batch(B, res, 7, dev)
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad()
         loss_fn(model(x), y).backward()
         opt.step()
     for _ in range(3):

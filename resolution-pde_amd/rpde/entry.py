@@ -25,6 +25,7 @@ def _init_distributed():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     return world, rank, local
