@@ -201,8 +201,14 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers); 
  * split-bf16 GEMMs -- faster, bit-identical output) */
 size_t rpde_feedforward_fwd_ws_bytes(int dim, int factor, int n_layers);
 /* 1 when rpde_feedforward_fwd (given its scratch) runs this shape as ONE fused kernel (dim 64, factor 4, three
- * layers: hidden activations never reach HBM).  Then hs / ds may be NULL in evaluation: only `out` is written;
- * with all of hs[0..1], ds[0..1] given the kernel also stores them and z_last for rpde_feedforward_bwd. */
+ * layers: hidden activations never reach HBM).  Pointer contract of the fused path, forward and backward alike:
+ *   hs and ds NULL ............ evaluation: only `out` is written;
+ *   hs[0..1] and ds[0..1] ..... training: h and d = gelu'(u) * dropscale of both hidden layers and z_last are
+ *                               stored by the forward and consumed by rpde_feedforward_bwd;
+ *   hs[0..1] only (ds NULL) ... training in recompute mode: hs receive u = dropout(z) and the backward kernels
+ *                               re-evaluate gelu / gelu' from them (half the saved bytes; measured slower).
+ * The weight gradients of these shapes come from the streaming kernel of csrc/wgrad_h2.hip (for the first layer
+ * together with grad_x), bias / gamma / beta gradients from per-workgroup partial sums folded in fixed order. */
 int rpde_feedforward_is_fused(int dim, int factor, int n_layers, int64_t P);
 int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual,
                          float* const* hs, float* const* ds, float* z_last, float* out, int64_t P,
