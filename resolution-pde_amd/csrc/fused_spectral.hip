@@ -446,6 +446,8 @@ __global__ __launch_bounds__(256, 2) void k_dft_synthesis2_h2(const SynP P) {
   // the 32 line scales in one vector load each (a scalar load per line would put its latency on every step)
   const float invx_l = P.invx[zx + li], invy_l = P.invy[zy + li];
   // lines go through in groups of four whose MFMA chains are interleaved; the next group's fragments are in flight
+  // (three groups in flight -- 12 lines, 238 VGPRs -- measured the same 338 us inside the training step: the kernel
+  //  is bound by the bandwidth between the L2 / Infinity Cache and the CUs, not by the latency of these loads)
   F f[8];
   auto line_src = [&](int i) { return i < 16 ? srcx + i * LB : srcy + (i - 16) * LB; };
 #pragma unroll
