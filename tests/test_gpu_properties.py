@@ -87,3 +87,28 @@ def test_spectralconv2d_is_linear_and_shift_equivariant(m, n, c, m1, m2, seed, s
         assert _rel(f(x1 - 2.0 * x2), y1 - 2.0 * f(x2)) < 5e-6
         sh = (sx % m, sy % n)
         assert _rel(f(torch.roll(x1, sh, dims=(2, 3))), torch.roll(y1, sh, dims=(2, 3))) < 5e-6
+
+
+@settings(**SET)
+@given(shape=st.sampled_from([(256, 256), (64, 256), (256, 64), (3, 64), (64, 1), (2, 128), (128, 3)]),
+       P=st.integers(8192, 40000), seed=st.integers(0, 10_000), a=st.floats(-3, 3), scale=st.sampled_from([1e-5, 1.0, 300.0]))
+def test_linear_weight_gradient_is_bilinear_and_matches_float64(shape, P, seed, a, scale):
+    """the streaming weight-gradient kernels (csrc/wgrad_h2.hip for the FeedForward shapes, csrc/thin_linear.hip for
+    lifting / projection shapes) at hypothesis-drawn point counts (tails of every length), operand scales and
+    combinations: gW(g, x) = g^T x is linear in g, and equals the float64 product"""
+    from rpde import ops
+    in_f, out_f = shape
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(P, in_f, generator=gen) * scale).to(DEV)
+    g1 = torch.randn(P, out_f, generator=gen).to(DEV)
+    g2 = torch.randn(P, out_f, generator=gen).to(DEV)
+    w = torch.zeros(out_f, in_f, device=DEV)
+
+    def gw(g):
+        ws = w.clone().requires_grad_(True)
+        ops.linear(x, ws, None).backward(g)
+        return ws.grad
+    d1, d2, d12 = gw(g1), gw(g2), gw(g1 + a * g2)
+    ref = g1.double().t() @ x.double()
+    assert _rel(d1, ref) < 3e-6
+    assert float((d12.double() - (d1.double() + a * d2.double())).norm()) < 1e-5 * float(ref.norm() * (1 + abs(a)))
