@@ -1,0 +1,10 @@
+// Streaming 1x1 convolution for channels-first tensors with at most 32 output channels (conv_small.hip).
+#pragma once
+#include "rpde_internal.h"
+
+namespace rpde {
+// Cout <= 32, S a multiple of 4, 16-byte aligned tensors; RPDE_CONV_SMALL=0 turns the path off
+bool conv1x1_small_ok(const float* x, const float* out, int Cin, int Cout, long S);
+int conv1x1_small(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, long S, int act_in,
+                  int accumulate, int act_out, hipStream_t st);
+}  // namespace rpde

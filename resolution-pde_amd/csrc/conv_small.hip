@@ -1,0 +1,89 @@
+// 1x1 convolution on channels-first tensors with few output channels (reference: nn.Conv1d/Conv2d(k=1) of the FNO
+// family -- lifting models/fno.py:30,93, the blocks' bypass conv models/fno_blocks.py:29,67, the projection's second
+// layer :39,77):   out[b][o][s] = act_out( (accumulate ? out[b][o][s] : 0) + bias[o] + sum_i W[o][i] act_in(x[b][i][s]) )
+// with Cout <= 32.  As a GEMM this is an [Cout x Cin] . [Cin x S] product per sample whose operands total a few KB of
+// weights against hundreds of MB of field: pure streaming.  A thread owns four consecutive grid points of one sample and
+// all Cout outputs (4 * Cout accumulators); it walks the input channels once -- every load is 16 B per lane, 1 KB
+// contiguous per wave -- with the weights read from LDS as broadcast 16-byte pieces.  The field is read once and the
+// output written once, at the HBM rate, where the generic GEMM path (activation staged into its k-loop, fp32 MFMA)
+// reaches about half of it.
+#include "rpde_internal.h"
+#include "conv_small.h"
+
+#include <stdlib.h>
+
+namespace rpde {
+
+template <int CO>      // outputs padded to CO in {4, 8, 16, 32}
+__global__ __launch_bounds__(256) void k_conv1x1_small(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int Cin,
+                                                       int Cout, long S, int act_in, int accumulate, int act_out) {
+  extern __shared__ float wt[];                  // [Cin][CO]: for one input channel the CO weights are contiguous
+  for (int e = threadIdx.x; e < Cin * CO; e += 256) {
+    const int i = e / CO, o = e % CO;
+    wt[e] = o < Cout ? w[o * Cin + i] : 0.f;
+  }
+  __syncthreads();
+  const long s4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (s4 >= S) return;
+  const int b = blockIdx.y;
+  const float* __restrict__ xb = x + (long)b * Cin * S + s4;
+  float* __restrict__ ob = out + (long)b * Cout * S + s4;
+  float4 acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    const float bo = (bias && o < Cout) ? bias[o] : 0.f;
+    acc[o] = make_float4(bo, bo, bo, bo);
+    if (accumulate && o < Cout) {
+      const float4 p = *reinterpret_cast<const float4*>(ob + (long)o * S);
+      acc[o].x += p.x; acc[o].y += p.y; acc[o].z += p.z; acc[o].w += p.w;
+    }
+  }
+  for (int i = 0; i < Cin; ++i) {
+    float4 v = *reinterpret_cast<const float4*>(xb + (long)i * S);
+    if (act_in) { v.x = act_f(act_in, v.x); v.y = act_f(act_in, v.y); v.z = act_f(act_in, v.z); v.w = act_f(act_in, v.w); }
+    const float4* __restrict__ wr = reinterpret_cast<const float4*>(wt + i * CO);
+#pragma unroll
+    for (int q = 0; q < CO / 4; ++q) {
+      const float4 ww = wr[q];
+      const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float4& a = acc[4 * q + k];
+        a.x = fmaf(wv[k], v.x, a.x); a.y = fmaf(wv[k], v.y, a.y); a.z = fmaf(wv[k], v.z, a.z); a.w = fmaf(wv[k], v.w, a.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    if (o < Cout) {
+      float4 a = acc[o];
+      if (act_out) { a.x = act_f(act_out, a.x); a.y = act_f(act_out, a.y); a.z = act_f(act_out, a.z); a.w = act_f(act_out, a.w); }
+      *reinterpret_cast<float4*>(ob + (long)o * S) = a;
+    }
+  }
+}
+
+bool conv1x1_small_ok(const float* x, const float* out, int Cin, int Cout, long S) {
+  const char* e = getenv("RPDE_CONV_SMALL");
+  if (e && e[0] == '0') return false;
+  return Cout >= 1 && Cout <= 32 && Cin >= 1 && Cin <= 512 && S % 4 == 0 &&
+         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+}
+
+int conv1x1_small(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, long S, int act_in,
+                  int accumulate, int act_out, hipStream_t st) {
+  const int CO = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : (Cout <= 16 ? 16 : 32));
+  const dim3 grid((unsigned)((S / 4 + 255) / 256), B), block(256);
+  const size_t lds = sizeof(float) * (size_t)Cin * CO;
+  switch (CO) {
+    case 4: hipLaunchKernelGGL(k_conv1x1_small<4>, grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out); break;
+    case 8: hipLaunchKernelGGL(k_conv1x1_small<8>, grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out); break;
+    case 16: hipLaunchKernelGGL(k_conv1x1_small<16>, grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out); break;
+    default: hipLaunchKernelGGL(k_conv1x1_small<32>, grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out); break;
+  }
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+}  // namespace rpde

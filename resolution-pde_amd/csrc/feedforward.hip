@@ -13,6 +13,7 @@
 #include "ff_fused.h"
 #include "wgrad_h2.h"
 #include "thin_linear.h"
+#include "conv_small.h"
 
 namespace rpde {
 
@@ -342,6 +343,10 @@ int rpde_conv1x1_fwd(const float* x, const float* w, const float* b, float* out,
 int rpde_conv1x1_act_fwd(const float* x, const float* w, const float* b, float* out, int B, int Cin, int Cout, int64_t S,
                          int act_in, int accumulate, int act_out, void* stream) {
   RPDE_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && S > 0 && S < (1L << 31), "conv1x1_fwd: bad arguments");
+  // (a thread walks all input channels for its four points: worth it once there are enough points to fill the chip --
+  //  the small 1-D configurations measured slower than the GEMM path)
+  if (conv1x1_small_ok(x, out, Cin, Cout, S) && B <= 65535 && (long)B * S >= (1L << 20))
+    return conv1x1_small(x, w, b, out, B, Cin, Cout, S, act_in, accumulate, act_out, as_stream(stream));
   rpde_gemm_desc d = gemm_desc();
   d.write_act = act_out;
   d.A = w; d.a_kmajor = 1; d.lda = Cin;

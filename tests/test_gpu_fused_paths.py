@@ -256,3 +256,35 @@ def test_thin_linear_kernels(gpu_device, in_f, out_f, P):
         tol = 2e-6 if name in ("y", "dx") else 1e-5      # dw, db: fp32 sums of up to 70001 signed terms (cancellation)
         assert _rel(a_, r_) < tol, (name, _rel(a_, r_))
         assert _rel(m_, r_) < tol, (name, "gemm", _rel(m_, r_))
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 32), (32, 32), (128, 1), (64, 2), (5, 20), (17, 7)])
+@pytest.mark.parametrize("act_in,act_out", [("identity", "identity"), ("gelu", "gelu"), ("relu", "identity")])
+def test_small_channel_conv_kernel(gpu_device, cin, cout, act_in, act_out):
+    """csrc/conv_small.hip (streaming 1x1 conv, Cout <= 32, channels-first) against the GEMM path
+    (RPDE_CONV_SMALL=0) and float64: plain, accumulating into the spectral branch's output, and the evaluation
+    form with the output activation in the epilogue"""
+    import torch.nn.functional as F
+    from rpde import ops
+    torch.manual_seed(cin * 100 + cout)
+    x = torch.randn(5, cin, 512, 412, device=gpu_device)              # 1.05 M points: above the kernel's size threshold
+    w = torch.randn(cout, cin, 1, 1, device=gpu_device) / cin ** 0.5
+    b = torch.randn(cout, device=gpu_device)
+    acc0 = torch.randn(5, cout, 512, 412, device=gpu_device)
+    act = {"identity": lambda t: t, "gelu": F.gelu, "relu": F.relu}
+
+    def run():
+        with torch.no_grad():
+            plain = ops.conv1x1(x, w, b, act_in)
+            accum = ops.conv1x1(x, w, b, act_in, acc=acc0.clone(), acc_owned=True)
+            ev = ops.conv1x1_act_eval(x, w, b, acc0.clone(), act_out)
+        return plain, accum, ev
+    got = run()
+    with _env(RPDE_CONV_SMALL="0"):
+        gemm = run()
+    lin = torch.einsum("oi,bihw->bohw", w[:, :, 0, 0].double(), act[act_in](x.double())) + b.double()[None, :, None, None]
+    lin0 = torch.einsum("oi,bihw->bohw", w[:, :, 0, 0].double(), x.double()) + b.double()[None, :, None, None]
+    refs = (lin, acc0.double() + lin, act[act_out](acc0.double() + lin0))
+    for name, a_, m_, r_ in zip(("plain", "accumulate", "eval"), got, gemm, refs):
+        assert _rel(a_, r_) < 2e-6, (name, _rel(a_, r_))
+        assert _rel(m_, r_) < 2e-6, (name, "gemm", _rel(m_, r_))
