@@ -84,6 +84,10 @@ class FlatAdamW(torch.optim.Optimizer):
         base_g = self.bucket.flat.data_ptr()
         live = []
         for i, p in enumerate(params):
+            r = 1 if p.is_complex() else 0
+            if p.data_ptr() != self._p[r].data_ptr() + 4 * (self._offsets[i] - self._bounds[r][0]):
+                raise RuntimeError("FlatAdamW: a parameter's storage changed after the optimizer was built (model.to(), "
+                                   "load with assign=True ...): build the optimizer after the model is in place")
             if p.grad is None:
                 continue
             if p.grad.data_ptr() != base_g + 4 * self._offsets[i]:     # .grad replaced after gather(): bring it in

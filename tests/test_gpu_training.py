@@ -434,3 +434,21 @@ def test_flat_adamw_matches_torch_adamw(gpu_device):
     for (n, a), b in zip(m_g.named_parameters(), m_e.parameters()):
         assert rel(a, b) < 5e-6, (n, rel(a, b))
     assert float(next(iter(o_g.state_dict()["state"].values()))["step"]) == 5.0
+
+
+def test_flat_adamw_refuses_moved_parameters(gpu_device):
+    from rpde.optim import FlatAdamW
+    lin = torch.nn.Linear(8, 8).to(gpu_device)
+    opt = FlatAdamW(lin.parameters(), lr=1e-3)
+    lin.weight.data = lin.weight.data.clone()                  # what model.to(other_device) / assign=True loading would do
+    opt.zero_grad()
+    lin(torch.randn(2, 8, device=gpu_device)).sum().backward()
+    with pytest.raises(RuntimeError, match="storage changed"):
+        opt.step()
+    # load_state_dict into the model (copy_ into the existing storage) is fine
+    lin2 = torch.nn.Linear(8, 8).to(gpu_device)
+    opt2 = FlatAdamW(lin2.parameters(), lr=1e-3)
+    lin2.load_state_dict(torch.nn.Linear(8, 8).state_dict())
+    opt2.zero_grad()
+    lin2(torch.randn(2, 8, device=gpu_device)).sum().backward()
+    opt2.step()
