@@ -4,8 +4,8 @@ The 1-D configurations (FNO1d / FFNO1D at batch 16) run ~100-170 small kernels p
 replayed, the step costs one graph launch on the host.  Measured on MI355X (profiles/other_configs.py): in round 1,
 with ~250 kernels of 8+ us each and torch's capturable AdamW (a dozen extra tiny kernels), no gain (1.54 ms eager
 vs 1.71 ms replayed); with the round-2 kernels and rpde.optim.FlatAdamW(capturable=True) the GPU side is short
-enough that host launches show: FNO1d 1024, B=16: 1.10 ms eager vs 0.74 ms replayed; FFNO1D 512, B=16: 1.72 vs
-1.53 ms.
+enough that host launches show: FNO1d 1024, B=16: 1.05 ms eager vs 0.72 ms replayed; FFNO1D 512, B=16: 1.62 vs
+1.50 ms.
 Everything the step does already is stream-ordered and allocation-free at the HIP level (workspaces come
 from torch's caching allocator, DFT plans are created on first use), so the capture needs no changes in the
 library -- only: plans and autotuned state must exist before capture (warm-up steps), the optimizer must be
