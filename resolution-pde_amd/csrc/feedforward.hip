@@ -258,14 +258,16 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
       if (both) RPDE_TRY(wgrad_h2_dgrad(buf1, x, p->weights[0], grad_weights[0], grad_x, P, p->dim, hid, slabs, st));
       else RPDE_TRY(linear_wgrad_impl(x, buf1, grad_weights[0], nullptr, P, p->dim, hid, slabs, small, st));
     }
-    if (grad_biases) {
-      RPDE_TRY(reduce_slabs(part, grad_biases[0], hid, grid, FF3_PART, 1.f, 0, st));
-      RPDE_TRY(reduce_slabs(part + 256, grad_biases[1], hid, grid, FF3_PART, 1.f, 0, st));
-      RPDE_TRY(reduce_slabs(part + 512, grad_biases[2], p->dim, grid, FF3_PART, 1.f, 0, st));
-    }
-    if (p->layer_norm) {
-      if (grad_gamma) RPDE_TRY(reduce_slabs(part + 576, grad_gamma, p->dim, grid, FF3_PART, 1.f, 0, st));
-      if (grad_beta) RPDE_TRY(reduce_slabs(part + 640, grad_beta, p->dim, grid, FF3_PART, 1.f, 0, st));
+    {   // per-workgroup partial sums -> the five small gradients, one launch
+      ReduceSegs sg;
+      memset(&sg, 0, sizeof(sg));
+      sg.n = FF3_PART; sg.nseg = 5;
+      const int off[5] = {0, 256, 512, 576, 640}, len[5] = {hid, hid, p->dim, p->dim, p->dim};
+      float* dst[5] = {grad_biases ? grad_biases[0] : nullptr, grad_biases ? grad_biases[1] : nullptr,
+                       grad_biases ? grad_biases[2] : nullptr, p->layer_norm ? grad_gamma : nullptr,
+                       p->layer_norm ? grad_beta : nullptr};
+      for (int k = 0; k < 5; ++k) { sg.off[k] = off[k]; sg.len[k] = len[k]; sg.dst[k] = dst[k]; }
+      RPDE_TRY(reduce_slabs_seg(part, grid, FF3_PART, sg, st));
     }
     return RPDE_OK;
   }

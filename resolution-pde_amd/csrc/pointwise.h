@@ -5,6 +5,9 @@
 namespace rpde {
 
 int reduce_slabs(const float* slabs, float* out, long n, int S, long stride, float scale, int accumulate, hipStream_t st);
+// out_k[j] = sum_s slabs[s*stride + off_k + j] for up to eight segments of one slab row, one launch; null dst: skipped
+struct ReduceSegs { int n, nseg; int off[8]; int len[8]; float* dst[8]; };
+int reduce_slabs_seg(const float* slabs, int S, long stride, const ReduceSegs& sg, hipStream_t st);
 constexpr int REDUCE_CHUNKS = 64;
 // tmp: REDUCE_CHUNKS * n floats of scratch
 int reduce_slabs_2pass(const float* slabs, float* out, long n, int S, long stride, float* tmp, hipStream_t st);

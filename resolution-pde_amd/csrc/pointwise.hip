@@ -44,6 +44,39 @@ int reduce_slabs(const float* slabs, float* out, long n, int S, long stride, flo
   return RPDE_OK;
 }
 
+// the same fold for a row of up to eight segments that go to different tensors (bias / gamma / beta gradients of the fused
+// FeedForward backward: one launch instead of five)
+__global__ __launch_bounds__(256) void k_reduce_slabs_seg(const float* __restrict__ slabs, int S, long stride, ReduceSegs sg) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  float acc = 0.f;
+  if (i < sg.n) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = ty;
+    for (; s + 28 < S; s += 32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += slabs[(long)(s + 4 * j) * stride + i];
+    }
+    for (; s < S; s += 4) a[0] += slabs[(long)s * stride + i];
+    acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < sg.n) {
+    acc = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < sg.nseg && i >= sg.off[k] && i < sg.off[k] + sg.len[k] && sg.dst[k]) sg.dst[k][i - sg.off[k]] = acc;
+  }
+}
+
+int reduce_slabs_seg(const float* slabs, int S, long stride, const ReduceSegs& sg, hipStream_t st) {
+  hipLaunchKernelGGL(k_reduce_slabs_seg, dim3((unsigned)((sg.n + 63) / 64)), dim3(256), 0, st, slabs, S, stride, sg);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
 // many slabs, few outputs (per-tile column sums): first fold S slabs into REDUCE_CHUNKS
 // partial rows (tmp [REDUCE_CHUNKS][n]) with one block per (64 outputs, chunk), then fold those
 __global__ __launch_bounds__(256) void k_reduce_slabs_chunk(const float* __restrict__ slabs, float* __restrict__ tmp, long n,
