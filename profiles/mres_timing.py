@@ -19,7 +19,8 @@ from rpde.optim import FlatAdamW  # noqa: E402
 opt = FlatAdamW(model.parameters(), lr=1e-3)
 loss_fn = RelativeL2Loss(size_average=True)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-for res in (64, 128, 256):
+RES = [int(r) for r in sys.argv[2].split(',')] if len(sys.argv) > 2 else [64, 128, 256]
+for res in RES:
     x, y = bench.synth_batch(B, res, 7, dev)
 
     def step():
