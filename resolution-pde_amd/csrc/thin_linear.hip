@@ -159,8 +159,9 @@ bool thin_linear_ok(int thin, int wide) {
   return thin >= 1 && thin <= 4 && wide >= 4 && wide <= 256 && wide % 4 == 0 && TL_THREADS % (wide / 4) == 0;
 }
 
-static int tl_grid(long work_items) {
-  long g = (work_items + 0) ;
+// grid-stride kernels: one workgroup per sweep up to 2048 workgroups (8 per CU)
+static int tl_grid(long sweeps) {
+  long g = sweeps;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   return (int)g;
