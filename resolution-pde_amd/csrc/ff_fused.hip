@@ -56,13 +56,15 @@ __global__ __launch_bounds__(1024) void k_ff3_prep(const float* __restrict__ w1,
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   // [0..2] max |W1|, |W2|, |W3|; [3] max row L1 of W1; [4] of W2; [5] max(|b1|), [6] max(|b2|) folded into 3,4 slots below
   float m1 = 0.f, m2 = 0.f, m3 = 0.f, r1 = 0.f, r2 = 0.f, bm = 0.f;
+#pragma unroll 8
   for (int i = tid; i < 256 * 64; i += 1024) { m1 = fmaxf(m1, fabsf(w1[i])); m3 = fmaxf(m3, fabsf(w3[i])); }
+#pragma unroll 16
   for (int i = tid; i < 256 * 256; i += 1024) m2 = fmaxf(m2, fabsf(w2[i]));
   for (int row = wv; row < 256; row += 16) {          // row L1 norms, one wave per row (coalesced)
     float a = fabsf(w1[row * 64 + l]);
     float b = (fabsf(w2[row * 256 + l]) + fabsf(w2[row * 256 + 64 + l])) + (fabsf(w2[row * 256 + 128 + l]) + fabsf(w2[row * 256 + 192 + l]));
-    r1 = fmaxf(r1, wave_sum(a));
-    r2 = fmaxf(r2, wave_sum(b));
+    r1 = fmaxf(r1, wave_sum_dpp(a));
+    r2 = fmaxf(r2, wave_sum_dpp(b));
   }
   if (tid < 256) {
     bm = fabsf(b1 ? b1[tid] : 0.f);
@@ -465,7 +467,9 @@ __global__ __launch_bounds__(1024) void k_ff3_prep_bwd(const float* __restrict__
   __shared__ float fin[5];
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   float m1 = 0.f, m2 = 0.f, m3 = 0.f, r3 = 0.f, r2 = 0.f;
+#pragma unroll 8
   for (int i = tid; i < 256 * 64; i += 1024) { m1 = fmaxf(m1, fabsf(w1[i])); m3 = fmaxf(m3, fabsf(w3[i])); }
+#pragma unroll 16
   for (int i = tid; i < 256 * 256; i += 1024) m2 = fmaxf(m2, fabsf(w2[i]));
   if (tid < 256) {               // column L1 norms: what bounds a row of the transposed products
     float a = 0.f, b = 0.f;

@@ -57,6 +57,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// sum over the wave, returned in every lane: the same six DPP steps with additions (out-of-row sources read as zero)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_step(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add_step<0x111, 0xf>(v);
+  v = dpp_add_step<0x112, 0xf>(v);
+  v = dpp_add_step<0x114, 0xf>(v);
+  v = dpp_add_step<0x118, 0xf>(v);     // lane 15 of each row: the row's sum
+  v = dpp_add_step<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3: lane 31 = rows 0+1, lane 63 = rows 2+3 (so far)
+  v = dpp_add_step<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3: lane 63 = everything
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // three-term product of split operands, small terms first
 __device__ __forceinline__ f32x4v h2_mfma32(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x4v c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
