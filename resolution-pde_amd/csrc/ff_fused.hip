@@ -245,8 +245,8 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
     // one scale per POINT (a column of the B operand): the four lanes that hold a point's 64 channels agree on its
     // maximum.  Points of very different magnitude inside a block then keep their own relative precision, which
     // the per-point LayerNorm at the end would otherwise expose
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = fmaxf(m, lane_xor16(m));
+    m = fmaxf(m, lane_xor32(m));
     float sc, iv;
     h2_scale(m, 0, sc, iv);
     char* dst = smem + FF_SBUF + (w * 2) * 2048 + l * 16;
@@ -412,12 +412,12 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
       // point to (mean, M2), the four are combined exactly (pairwise update of Chan et al.): as accurate as the
       // reference's two-pass variance, with one exchange through LDS
       float sum = (v[0] + v[1]) + (v[2] + v[3]);
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum += lane_xor16(sum);
+      sum += lane_xor32(sum);
       const float mw = sum * (1.f / 16.f);
       float m2 = (v[0] - mw) * (v[0] - mw) + (v[1] - mw) * (v[1] - mw) + (v[2] - mw) * (v[2] - mw) + (v[3] - mw) * (v[3] - mw);
-      m2 += __shfl_xor(m2, 16, 64);
-      m2 += __shfl_xor(m2, 32, 64);
+      m2 += lane_xor16(m2);
+      m2 += lane_xor32(m2);
       if (g == 0) *reinterpret_cast<float2*>(stat + ((b3 * 4 + t3) * 16 + li) * 2) = make_float2(mw, m2);
     }
     lds_barrier();                         // B3: per-wave statistics are in LDS (also: everyone is done with h2 / stats of the previous tile)
@@ -629,12 +629,12 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
     float dz[4], dzb;
     if (A.layer_norm) {
       float sum = (tz[0] + tz[1]) + (tz[2] + tz[3]);
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum += lane_xor16(sum);
+      sum += lane_xor32(sum);
       const float mw = sum * (1.f / 16.f);
       float m2 = (tz[0] - mw) * (tz[0] - mw) + (tz[1] - mw) * (tz[1] - mw) + (tz[2] - mw) * (tz[2] - mw) + (tz[3] - mw) * (tz[3] - mw);
-      m2 += __shfl_xor(m2, 16, 64);
-      m2 += __shfl_xor(m2, 32, 64);
+      m2 += lane_xor16(m2);
+      m2 += lane_xor32(m2);
       if (g == 0) *reinterpret_cast<float2*>(stat1 + ((b3 * 4 + t3) * 16 + li) * 2) = make_float2(mw, m2);
       lds_barrier();                                                                  // A
       float mws[4], m2s = 0.f, mean = 0.f;
@@ -663,9 +663,9 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
         s2 += dxh[k] * xh[k];
         am = fmaxf(am, fabsf(dxh[k]));
       }
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      am = fmaxf(am, __shfl_xor(am, 16, 64)); am = fmaxf(am, __shfl_xor(am, 32, 64));
+      s1 += lane_xor16(s1); s1 += lane_xor32(s1);
+      s2 += lane_xor16(s2); s2 += lane_xor32(s2);
+      am = fmaxf(am, lane_xor16(am)); am = fmaxf(am, lane_xor32(am));
       if (g == 0) *reinterpret_cast<float4*>(stat2 + ((b3 * 4 + t3) * 16 + li) * 4) = make_float4(s1, s2, am, rstd);
       // gamma / beta gradients: sum over the 16 points of the block, one writer per (block, feature)
 #pragma unroll
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       float am = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { dz[k] = gy[k] * dact_f(A.post_act, tz[k]) * s4[k]; am = fmaxf(am, fabsf(dz[k])); }
-      am = fmaxf(am, __shfl_xor(am, 16, 64)); am = fmaxf(am, __shfl_xor(am, 32, 64));
+      am = fmaxf(am, lane_xor16(am)); am = fmaxf(am, lane_xor32(am));
       if (g == 0) stat2[((b3 * 4 + t3) * 16 + li) * 4] = am;
       lds_barrier();                                                                  // B (A is not needed)
       float AM = 0.f;

@@ -72,6 +72,21 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// the value held by lane l ^ 16 / l ^ 32, by gfx950's v_permlane16_swap / v_permlane32_swap (vector ALU: no trip through
+// the LDS crossbar as __shfl_xor takes).  swap(v, v) returns {v with its odd rows (upper half) replaced by the even rows
+// (lower half), v with its even rows (lower half) replaced by the odd rows (upper half)}: each lane picks the copy in
+// which its own position was overwritten by its partner.
+__device__ __forceinline__ float lane_xor16(float v) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float((threadIdx.x & 16) ? r.x : r.y);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r.x : r.y);
+}
+
 // three-term product of split operands, small terms first
 __device__ __forceinline__ f32x4v h2_mfma32(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x4v c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
