@@ -16,6 +16,7 @@
 #include "plan.h"
 #include "pointwise.h"
 #include "cf_dft.h"
+#include "h2.h"
 
 namespace rpde {
 
@@ -35,7 +36,7 @@ __device__ __forceinline__ const float* wsel(const float* w1, const float* w2, c
 //   MODE 2  gW[i,o]  = sum_b conj(s[b,i]) g[b,o]      (reduction over b)
 // per retained mode (r, ky).  A wave owns one (row r, kept channel) pair: lanes 0..15 of each 16-lane group are 16
 // consecutive ky (the contiguous index of both the spectra and the weights: 64 / 128-byte coalesced segments), the
-// four lane groups split the reduction index four ways and are combined with two wave shuffles at the end.  The
+// four lane groups split the reduction index four ways and are combined with two lane-swap additions (v_permlane16_swap, v_permlane32_swap) at the end.  The
 // eight waves of a workgroup share one row r of the spectra, staged in LDS in chunks of the reduction index, so the
 // spectra are read from memory once per workgroup and every weight exactly once per launch.
 constexpr int CMIX_WAVES = 8;
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(64 * CMIX_WAVES) void k_cmix(const float* __restric
     // combine the four lane groups (reduction index mod 4)
 #pragma unroll
     for (int b = 0; b < (MODE == 2 ? 1 : MAXB); ++b) {
-      accr[b] += __shfl_xor(accr[b], 16, 64); accr[b] += __shfl_xor(accr[b], 32, 64);
-      acci[b] += __shfl_xor(acci[b], 16, 64); acci[b] += __shfl_xor(acci[b], 32, 64);
+      accr[b] += lane_xor16(accr[b]); accr[b] += lane_xor32(accr[b]);
+      acci[b] += lane_xor16(acci[b]); acci[b] += lane_xor32(acci[b]);
     }
     if (live && kyok && grp == 0) {
       if (MODE == 2) {
