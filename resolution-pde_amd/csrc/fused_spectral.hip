@@ -585,6 +585,7 @@ int fused2d_synthesis(const void* imgy, const void* imgx, const float* invy, con
   P.imgy = (const char*)imgy; P.imgx = (const char*)imgx; P.invy = invy; P.invx = invx;
   P.taby = (const char*)py->h2_syn[adjoint]; P.tabx = (const char*)px->h2_syn[adjoint];
   P.out = out; P.skip = skip; P.B = B; P.M = M; P.N = N;
+  // (super-tile side, measured at B = 32, 256^2, forward + backward: 2 -> 1.52 ms, 4 -> 1.44, 8 -> 1.45, 16 -> 1.53)
   auto side = [](int tiles) { int s = tiles < 8 ? tiles : 8; while (tiles % s) --s; return s; };
   P.sy = side(M / 16); P.sx = side(N / 16);
   const int R = 2 * py->kp;
