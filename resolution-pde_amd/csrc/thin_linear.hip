@@ -205,10 +205,11 @@ int thin_contract(const float* a, const float* w, long ws_t, long ws_o, const fl
   return RPDE_OK;
 }
 
-// at least 128 points per workgroup (a sweep of 256 threads covers 4 .. 64 of them), at most 1024 workgroups
+// at least 128 points per workgroup (a sweep of 256 threads covers 4 .. 64 of them), at most 256 workgroups: the
+// fold that follows is a handful of workgroups reading every slab (1024 slabs made it 65 us at 2 M points)
 static int tl_outer_blocks(long P) {
   long nb = (P + 127) / 128;
-  if (nb > 1024) nb = 1024;
+  if (nb > 256) nb = 256;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
