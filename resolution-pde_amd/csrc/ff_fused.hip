@@ -295,7 +295,9 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
       sh2 = a; inv3 = ai * winv3;
     };
 
-    // (tried and dropped, same-box A/B: different block orders for the two waves of a SIMD in layer 2 -- matrix,
+    // (tried and dropped, same-box A/B: s_setprio(2) around the layer-2 matrix chain (evaluation -1.3 .. -2 %, training
+    //  -2.6 % on one box and +0.9 % on another: not a robust gain; around every chain of the forward, backward and
+    //  weight-gradient kernels: worse); different block orders for the two waves of a SIMD in layer 2 -- matrix,
     //  activation, matrix, activation against matrix, matrix, activation, activation -- 1.81 vs 1.82 ms in evaluation,
     //  2.74 vs 2.62 ms in training (5 spills); the activation pair in packed fp32 (v_pk_fma_f32 chains for two elements: 1.86
     //  vs 1.85 ms in evaluation, 2.78 vs 2.62 ms in training -- packed fp32 issues no faster here); a run without
