@@ -22,7 +22,10 @@ def _init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # RPDE_FORCE_DIST=1: join the process group even as a single rank, so that a 1-GPU box exercises the RCCL path
+    # (librccl load, communicator init, the gradient all-reduce on the launch stream): tests/test_gpu_rccl.py
+    force = os.environ.get("RPDE_FORCE_DIST") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
@@ -193,7 +196,7 @@ def run(dims: int, argv=None):
                     "loss_history": loss_hist, "val_loss_history": val_hist, "l2_loss": test_l2,
                     "resolution_rel_l2": resolution_results}, path)
         print(json.dumps({"checkpoint": path}), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return test_l2

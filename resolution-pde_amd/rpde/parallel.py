@@ -13,6 +13,7 @@ concatenated batch).
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List
 
 import torch
@@ -98,7 +99,9 @@ class FlatGradBucket:
 
     def all_reduce_mean(self) -> None:
         self.gather()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # (a single rank skips the collective unless RPDE_FORCE_DIST=1 asks for it: the 1-GPU RCCL rehearsal)
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or
+                                                              os.environ.get("RPDE_FORCE_DIST") == "1"):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / dist.get_world_size())
 

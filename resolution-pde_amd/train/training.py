@@ -15,6 +15,7 @@ Differences, all on the host side of the hot path:
 from __future__ import annotations
 
 import json
+import os
 from typing import Callable, Optional
 
 import torch
@@ -25,7 +26,9 @@ from utils.loss import RelativeL2Loss
 
 
 def _dist_on() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # (RPDE_FORCE_DIST=1: a single rank still runs its collectives -- the 1-GPU RCCL rehearsal, rpde/entry.py)
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or
+                                                              os.environ.get("RPDE_FORCE_DIST") == "1")
 
 
 def _mean_over_ranks(total: torch.Tensor, count: int) -> float:

@@ -98,6 +98,9 @@ CASES = [
     dict(name="ffno2d_cfg3_64", kind="FFNO2D", ctor=FFNO2D_CFG3, x=(2, 1, 64, 64), seed=511),
     dict(name="ffno2d_cfg3_128", kind="FFNO2D", ctor=FFNO2D_CFG3, x=(1, 1, 128, 128), seed=512),
     dict(name="ffno2d_cfg3_256", kind="FFNO2D", ctor=FFNO2D_CFG3, x=(1, 1, 256, 256), seed=513),
+    # the headline configuration at a real batch (P = 524 288 grid points per layer; ~9 GB of autograd state in the
+    # reference run): pins batch handling -- slab counts, grid decompositions, 64-bit offsets -- against the reference
+    dict(name="ffno2d_cfg3_256_b8", kind="FFNO2D", ctor=FFNO2D_CFG3, x=(8, 1, 256, 256), seed=515),
     dict(name="ffno2d_small_nowm", kind="FFNO2D",
          ctor=dict(in_channels=2, out_channels=3, width=16, n_layers=2, n_modes=5, factor=2, ff_weight_norm=False,
                    n_ff_layers=2, layer_norm=False, dropout=0.0, use_grid=False),
