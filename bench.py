@@ -10,12 +10,16 @@ and no WORLD_SIZE in the environment the script spawns its N ranks itself
 (rpde/launch.py); under torch.distributed.run it is one of them.  Rank 0 prints
 ONE JSON line.  It also carries
   * roofline: the dominant kernel -- k_ff3_fwd_h2<1>, the fused FeedForward
-    64->256->256->64 forward of one layer in training mode (reads x and the
-    residual, writes out, z3 and the saved h1, d1, h2, d2) -- timed live with
-    HIP events on the launch stream: algorithmic bytes per launch / time
-    against 8 TB/s; roofline_extra: the same kernel in evaluation, the fused
-    backward chain, the streaming weight-gradient kernel, the spectral
-    backward and the BASELINE config-5 SpectralConv2d forward;
+    64->256->256->64 forward of one layer in training mode -- timed live with
+    HIP events on the launch stream.  SURVEY 8(d) prices FeedForward against
+    the MATRIX roof: flops = 2*P*(64*256 + 256*256 + 256*64) = 12.88 GFLOP
+    per sample; every fp32 product is issued as three f16 MFMA products
+    (csrc/h2.h), so achieved = 3 * flops / time against the 2.5 PFLOP/s dense
+    f16 peak.  roofline_extra: the same kernel's HBM view (its saved-for-
+    backward stash labelled as design traffic, not algorithmic bytes), the
+    kernel in evaluation, the fused backward chain, the streaming
+    weight-gradient kernel, the spectral backward and the BASELINE config-5
+    SpectralConv2d forward;
   * roofline_spectral: the FSpectralConv2d.forward_fourier pipeline (fused h2
     analysis / synthesis kernels), algorithmic bytes (33.55 MB*B +
     1.31 MB per layer forward) against 8 TB/s;
@@ -24,6 +28,10 @@ ONE JSON line.  It also carries
   * cpu_baseline: the CPU oracle's training step timed on the host cores
     (rank 0, N=1 only, bounded sample: batch 4, 2 warm-up + 5 timed steps,
     and one single-thread step);
+  * gpu_aten_baseline: the SAME oracle (the reference's op sequence: permute,
+    rfft, einsum, irfft ... on hipFFT/rocFFT + hipBLASLt through ATen) run on
+    the GPU beside the HIP path -- the "why not rocFFT" A/B of DESIGN.md
+    section 2 (checker code, never on the product path);
   * parity: forward rel-L2 of the HIP path vs the oracle on identical inputs.
 """
 from __future__ import annotations
@@ -137,8 +145,21 @@ def time_feedforward(B, device, iters=10):
         _lib.check(lib.rpde_feedforward_bwd(C.byref(fp), x.data_ptr(), C.cast(ha, PP), C.cast(da, PP), z3.data_ptr(), gout.data_ptr(),
                                             None, None, None, None, None, P, wsb.data_ptr(), nbw, st), "ff bwd")
 
+    # the complete backward as a training step runs it: chain + three weight gradients (+ dx) + bias / LayerNorm sums
+    gx = torch.empty(P, dim, device=device)
+    gws = [torch.empty_like(w) for w in ws_]
+    gbs = [torch.empty_like(b) for b in bs_]
+    ggam, gbet = torch.empty(dim, device=device), torch.empty(dim, device=device)
+    gwa, gba = _lib.ptr_array(gws), _lib.ptr_array(gbs)
+
+    def bwd_full():
+        _lib.check(lib.rpde_feedforward_bwd(C.byref(fp), x.data_ptr(), C.cast(ha, PP), C.cast(da, PP), z3.data_ptr(), gout.data_ptr(),
+                                            gx.data_ptr(), C.cast(gwa, PP), C.cast(gba, PP), ggam.data_ptr(), gbet.data_ptr(), P,
+                                            wsb.data_ptr(), nbw, st), "ff bwd (all gradients)")
+
     assert lib.rpde_feedforward_is_fused(dim, 4, 3, P) == 1, "the fused FeedForward kernel does not cover the headline shape"
     t_ft = _ev_time(fwd_train, iters)
+    t_bf = _ev_time(bwd_full, iters)
     t_fe = _ev_time(fwd_eval, iters)
     t_bc = _ev_time(bwd_chain, iters)
     # the 256 x 256 weight gradient, as rpde_feedforward_bwd launches it: k_wgrad_h2 + the fixed-order slab reduction
@@ -154,7 +175,7 @@ def time_feedforward(B, device, iters=10):
     by_train = 4.0 * P * (4 * dim + 4 * hid)            # x, residual, out, z3 + h1, d1, h2, d2
     by_eval = 4.0 * P * 3 * dim                         # x, residual, out
     by_chain = 4.0 * P * (3 * dim + 4 * hid)            # g, z3, dz3 + d2, d1, du2, du1
-    return {"fwd_train_ms": t_ft, "fwd_eval_ms": t_fe, "bwd_chain_ms": t_bc, "wgrad_ms": t_wg, "flops_fwd": flops_fwd,
+    return {"fwd_train_ms": t_ft, "fwd_eval_ms": t_fe, "bwd_chain_ms": t_bc, "bwd_full_ms": t_bf, "wgrad_ms": t_wg, "flops_fwd": flops_fwd,
             "bytes_train": by_train, "bytes_eval": by_eval, "bytes_chain": by_chain, "flops_wgrad": 2.0 * P * hid * hid,
             "bytes_wgrad": 8.0 * P * hid}
 
@@ -177,7 +198,7 @@ def time_spectral(B, device, iters=10):
 
     ms_fb = _ev_time(fb, iters, warm=2)
     alg_bytes = 4.0 * B * RES * RES * 2 * 64 + 2 * 8.0 * 64 * 64 * 20
-    return ms, alg_bytes / (ms * 1e-3) / 1e9, alg_bytes, ms_fb - ms
+    return ms, alg_bytes / (ms * 1e-3) / 1e9, alg_bytes, ms_fb - ms, ms_fb
 
 
 def time_cfg5(device, B=8, iters=10):
@@ -198,6 +219,72 @@ def time_cfg5(device, B=8, iters=10):
         u = torch.randn(B, 1, 512, 512, generator=g).to(device)
         ms_model = _ev_time(lambda: model(u), iters)
     return ms, 67.11e6 * B + 2.36e6, ms_model
+
+
+def gpu_aten_baseline(B, device, hip_spec_ms, hip_spec_fb_ms, hip_ff_fwd_ms, hip_ff_fb_ms, hip_step_ms):
+    """The reference's own op sequence on this GPU through stock ATen (hipFFT/rocFFT for rfft/irfft, hipBLASLt/rocBLAS
+    for einsum/linear): oracle/reference_path.py on cuda tensors.  Baseline leg only (like cpu_baseline); the product
+    path never touches it.  Times the spectral pipeline (models/spectral_convolution.py:256-318) and the FeedForward
+    (models/custom_layer.py:49-68) of one FFNO2D layer at [B,256,256,64], forward and forward+backward, and the whole
+    training step at batch B."""
+    from models.ffno import FFNO2D
+    from oracle import reference_path as R
+    g = torch.Generator(device="cpu").manual_seed(17)
+    x = torch.randn(B, RES, RES, 64, generator=g).to(device)
+    wy = (torch.randn(64, 64, 20, 2, generator=g) * 0.1).to(device)
+    wx = (torch.randn(64, 64, 20, 2, generator=g) * 0.1).to(device)
+    alg = 4.0 * B * RES * RES * 2 * 64 + 2 * 8.0 * 64 * 64 * 20
+    out = {}
+    with torch.no_grad():
+        ms = _ev_time(lambda: R.fspectral2d_fourier(x, wy, wx, 20), 5, warm=2)
+    xg, wyg, wxg = x.clone().requires_grad_(True), wy.clone().requires_grad_(True), wx.clone().requires_grad_(True)
+    cot = torch.randn_like(x)
+
+    def fb():
+        R.fspectral2d_fourier(xg, wyg, wxg, 20).backward(cot)
+        xg.grad = wyg.grad = wxg.grad = None
+    ms_fb = _ev_time(fb, 5, warm=2)
+    out["spectral_fwd"] = {"aten_ms": round(ms, 3), "hip_ms": round(hip_spec_ms, 3), "aten_algorithmic_GBps": round(alg / ms / 1e6, 1),
+                           "hip_algorithmic_GBps": round(alg / hip_spec_ms / 1e6, 1), "speedup": round(ms / hip_spec_ms, 2)}
+    out["spectral_fwd_bwd"] = {"aten_ms": round(ms_fb, 3), "hip_ms": round(hip_spec_fb_ms, 3), "speedup": round(ms_fb / hip_spec_fb_ms, 2)}
+    del xg, cot
+    torch.manual_seed(3)
+    model = FFNO2D(**CFG3).to(device)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    pfx = "fourier_layers.0.backcast_ff."
+    x2 = x.reshape(-1, 64)
+    with torch.no_grad():
+        ms = _ev_time(lambda: R.feedforward(x2, sd, pfx, 3, True, 0.1, True), 5, warm=2)
+    params = R.make_params({k: v for k, v in sd.items() if k.startswith(pfx)})
+    x2g = x2.clone().requires_grad_(True)
+    cot2 = torch.randn_like(x2)
+
+    def ffb():
+        R.feedforward(x2g, params, pfx, 3, True, 0.1, True).backward(cot2)
+        x2g.grad = None
+        for p_ in params.values():
+            p_.grad = None
+    ms_fb = _ev_time(ffb, 5, warm=2)
+    out["feedforward_fwd_train"] = {"aten_ms": round(ms, 3), "hip_ms": round(hip_ff_fwd_ms, 3), "speedup": round(ms / hip_ff_fwd_ms, 2)}
+    out["feedforward_fwd_bwd"] = {"aten_ms": round(ms_fb, 3), "hip_ms": round(hip_ff_fb_ms, 3), "speedup": round(ms_fb / hip_ff_fb_ms, 2)}
+    del x2g, cot2, x, x2
+    # the whole training step (fwd + rel-L2 + bwd + AdamW, dropout 0.1) of the oracle on the GPU
+    params = R.make_params(sd)
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-3)
+    xb, yb = synth_batch(B, RES, 99, device)
+    fwd = lambda p, xx: R.ffno2d_forward(p, xx, CFG3["n_layers"], CFG3["n_modes"], CFG3["n_ff_layers"],  # noqa: E731
+                                         CFG3["layer_norm"], CFG3["dropout"], training=True)
+
+    def step():
+        opt.zero_grad()
+        R.relative_l2(fwd(params, xb), yb).backward()
+        opt.step()
+    ms = _ev_time(step, 3, warm=2)
+    out["train_step"] = {"aten_ms": round(ms, 2), "hip_ms": round(hip_step_ms, 2), "aten_samples_per_s": round(B / ms * 1e3, 1),
+                         "speedup": round(ms / hip_step_ms, 2)}
+    out["what"] = ("oracle/reference_path.py (the reference's op sequence) on cuda tensors: ATen -> hipFFT/rocFFT, hipBLASLt/rocBLAS, "
+                   f"ATen elementwise kernels; fp32, batch {B}, 256^2; hip = this repository's kernels, same shapes, same run")
+    return out
 
 
 def host_cores() -> int:
@@ -273,10 +360,11 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)      # 10 warm-up + 50 timed
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aten-baseline", action="store_true", help="skip the stock-ATen-on-GPU A/B leg")
     ap.add_argument("--steps-only", action="store_true",
                     help="profiling aid: stop after the timed training steps (no kernel microbenchmarks, no parity leg)")
     args = ap.parse_args()
@@ -377,20 +465,21 @@ def main():
         ff = time_feedforward(B, device)
         log(f"FeedForward: fwd(train) {ff['fwd_train_ms']:.3f} ms, fwd(eval) {ff['fwd_eval_ms']:.3f} ms, "
             f"bwd chain {ff['bwd_chain_ms']:.3f} ms, wgrad {ff['wgrad_ms']:.3f} ms")
-        s_ms, s_gbs, s_bytes, s_bwd_ms = time_spectral(B, device)
+        s_ms, s_gbs, s_bytes, s_bwd_ms, s_fb_ms = time_spectral(B, device)
         log(f"spectral fwd {s_ms:.3f} ms = {s_gbs:.0f} GB/s algorithmic; bwd {s_bwd_ms:.3f} ms")
         c5_ms, c5_bytes, c5_model_ms = time_cfg5(device)
         log(f"config 5: SpectralConv2d 512^2 forward {c5_ms:.3f} ms, FNO2d eval forward {c5_model_ms:.3f} ms (B=8)")
-        traffic = step_traffic = traffic_src = None
+        traffic = step_traffic = traffic_src = spec_traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 blob = json.load(open(tpath))
                 traffic = blob.get("dominant_kernel", {}).get(f"B{B}")
+                spec_traffic = blob.get("spectral_forward", {}).get(f"B{B}")
                 step_traffic = blob.get("train_step", {}).get(f"B{B}", {}).get("hbm_bytes_per_step")
                 traffic_src = blob.get("source")
             except Exception:
-                traffic = step_traffic = None
+                traffic = step_traffic = spec_traffic = None
 
         def hbm(kernel, byt, ms, **extra):
             gbs = byt / (ms * 1e-3) / 1e9
@@ -416,14 +505,27 @@ def main():
             # fp32 in / out / accumulate everywhere.  Products run on the f16 matrix pipe by two-piece splitting with
             # dynamic power-of-two scaling (3 MFMA terms, csrc/h2.h) in the fused kernels and on the bf16 pipe by
             # three-piece splitting (6 terms) in the remaining GEMMs.
-            "roofline": hbm("k_ff3_fwd_h2<train>: fused FeedForward 64->256->256->64 forward of one layer (+ weight preparation, "
-                            "1 block): reads x, residual; writes out, z3 and the saved h1, d1, h2, d2",
-                            ff["bytes_train"], ff["fwd_train_ms"], traffic=traffic, traffic_source=traffic_src,
-                            flops_per_launch=ff["flops_fwd"], fp32_equiv_tflops=tf(ff["flops_fwd"], ff["fwd_train_ms"]),
-                            frac_of_h2_matrix_roof=round(tf(ff["flops_fwd"], ff["fwd_train_ms"]) / (PEAK_BF16_MFMA_TF / 3), 4),
-                            note="hidden activations never leave the CU; the kernel is bound by the vector work of "
-                                 "bias + dropout + GELU + GELU' (SQ counters in profiles/), not by HBM or the matrix pipe"),
+            # FeedForward is priced against the matrix roof.  flops_per_launch = 2*P*(64*256 + 256*256 +
+            # 256*64) = 12.88 GFLOP * B; the kernel issues every fp32 product as THREE f16 MFMA products (h2.h), so the
+            # matrix pipe executes 3x that: achieved = issued flops / time, peak = 2.5 PFLOP/s dense f16
+            "roofline": {"kernel": "k_ff3_fwd_h2<train>: fused FeedForward 64->256->256->64 forward of one layer (+ its weight "
+                                   "preparation launch)",
+                         "bound": "mfma", "achieved": tf(3.0 * ff["flops_fwd"], ff["fwd_train_ms"]), "peak": PEAK_BF16_MFMA_TF,
+                         "unit": "TFLOP/s", "frac": round(tf(3.0 * ff["flops_fwd"], ff["fwd_train_ms"]) / PEAK_BF16_MFMA_TF, 4),
+                         "flops_per_launch": ff["flops_fwd"], "issued_flops_per_launch": 3.0 * ff["flops_fwd"],
+                         "issued_flops": "3x: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_16x16x32_f16, fp32 accumulate",
+                         "fp32_equiv_tflops": tf(ff["flops_fwd"], ff["fwd_train_ms"]),
+                         "frac_of_fp32_mfma_peak": round(tf(ff["flops_fwd"], ff["fwd_train_ms"]) / PEAK_F32_MFMA_TF, 4),
+                         "ms_per_launch": round(ff["fwd_train_ms"], 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "fp32 in / out / accumulate; hidden activations never leave the CU.  Neither roof is near: "
+                                 "the kernel is bound by VALU issue (bias, dropout, GELU + GELU', f16 splitting, LayerNorm) -- "
+                                 "SQ counters in profiles/"},
             "roofline_extra": [
+                hbm("k_ff3_fwd_h2<train>, HBM view: reads x, residual; writes out, z3 (algorithmic: 4*P*2C + weights = "
+                    f"{(4.0 * B * RES * RES * 2 * 64 + 4 * 98304) / 1e9:.2f} GB) plus the saved-for-backward stash h1, d1, h2, d2 "
+                    "(DESIGN TRAFFIC, not algorithmic: 4 x [P,256] fp32)", ff["bytes_train"], ff["fwd_train_ms"],
+                    algorithmic_bytes_8d=4.0 * B * RES * RES * 2 * 64 + 4 * 98304, design_stash_bytes=4.0 * B * RES * RES * 4 * 256,
+                    traffic=traffic),
                 hbm("k_ff3_fwd_h2<eval>: the same forward in evaluation (writes nothing but the output)", ff["bytes_eval"],
                     ff["fwd_eval_ms"], fp32_equiv_tflops=tf(ff["flops_fwd"], ff["fwd_eval_ms"])),
                 hbm("k_ff3_bwd_h2: LayerNorm/dropout adjoint + data-gradient chain (reads g, z3, d2, d1; writes dz3, du2, du1)",
@@ -439,7 +541,10 @@ def main():
             ],
             "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_dft_analysis_h2 (both axes, one launch) + mode mix "
                                      "(2 GEMM) + k_spec_split_h2 (2) + k_dft_synthesis2_h2 (field written once)",
-                                     s_bytes, s_ms, note="x is read twice (once per axis; partial sums of the other axis "
+                                     s_bytes, s_ms, traffic=spec_traffic,
+                                     traffic_over_algorithmic=(round(spec_traffic / s_bytes, 3) if spec_traffic else None),
+                                     backward_ms=round(s_bwd_ms, 4), backward_frac=round(2 * s_bytes / (s_bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                     note="x is read twice (once per axis; partial sums of the other axis "
                                      "would be larger than the field), so 1.5x the algorithmic bytes is the floor of this "
                                      "formulation: frac <= 0.52 at the 6.3 TB/s this box streams"),
         }
@@ -457,6 +562,10 @@ def main():
                 line["cpu_baseline"] = cpu_baseline()
                 log(f"cpu baseline {line['cpu_baseline']['value']} samples/s")
                 line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
+            if not args.no_aten_baseline:
+                line["gpu_aten_baseline"] = gpu_aten_baseline(B, device, s_ms, s_fb_ms, ff["fwd_train_ms"],
+                                                              ff["fwd_train_ms"] + ff["bwd_full_ms"], ms_step)
+                log(f"stock ATen on this GPU: {json.dumps(line['gpu_aten_baseline'])}")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

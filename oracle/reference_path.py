@@ -241,8 +241,8 @@ def ffno2d_forward(sd: Mapping[str, Tensor], x: Tensor, n_layers: int, n_modes: 
                    mode: str = "full", use_grid: bool = True, training: bool = False) -> Tensor:
     b, _, m, n = x.shape
     if use_grid:
-        gx = _lin(0.0, 1.0, m).reshape(1, 1, m, 1).repeat(b, 1, 1, n)
-        gy = _lin(0.0, 1.0, n).reshape(1, 1, 1, n).repeat(b, 1, m, 1)
+        gx = _lin(0.0, 1.0, m).reshape(1, 1, m, 1).repeat(b, 1, 1, n).to(x.device)
+        gy = _lin(0.0, 1.0, n).reshape(1, 1, 1, n).repeat(b, 1, m, 1).to(x.device)
         x = torch.cat((x, gx, gy), dim=1)
     h = wn_linear(x.permute(0, 2, 3, 1), sd, "in_proj.")
     for i in range(n_layers):

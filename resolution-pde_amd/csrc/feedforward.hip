@@ -24,6 +24,9 @@ static inline uint64_t layer_seed(uint64_t seed, int l) {
   return z ^ (z >> 31);
 }
 
+// the thin-linear kernels move the wide operand as float4: a view with an odd storage offset takes the GEMM path
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 static inline int ff_in(const rpde_ff_params* p, int l) { return l == 0 ? p->dim : p->dim * p->factor; }
 static inline int ff_out(const rpde_ff_params* p, int l) { return l == p->n_layers - 1 ? p->dim : p->dim * p->factor; }
 
@@ -47,8 +50,8 @@ static int linear_fwd_impl(const float* x, const float* w, const float* b, float
                            void* wimg = nullptr) {
   if (act_out == RPDE_ACT_IDENTITY && !dy && drop_p == 0.f) {
     // lifting / projection shapes: streaming kernels instead of degenerate GEMMs (thin_linear.hip)
-    if (in_f <= 4 && thin_linear_ok(in_f, out_f)) return thin_expand(x, w, in_f, 1, b, y, P, in_f, out_f, st);
-    if (out_f <= 4 && thin_linear_ok(out_f, in_f)) return thin_contract(x, w, in_f, 1, b, y, P, out_f, in_f, st);
+    if (in_f <= 4 && thin_linear_ok(in_f, out_f) && al16(y)) return thin_expand(x, w, in_f, 1, b, y, P, in_f, out_f, st);
+    if (out_f <= 4 && thin_linear_ok(out_f, in_f) && al16(x)) return thin_contract(x, w, in_f, 1, b, y, P, out_f, in_f, st);
   }
   rpde_gemm_desc d = gemm_desc();
   d.A = x; d.a_kmajor = 1; d.lda = in_f;
@@ -71,8 +74,8 @@ static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* 
                              float* ws_slabs, float* ws_colsum, hipStream_t st, int act_x = RPDE_ACT_IDENTITY) {
   if (act_x == RPDE_ACT_IDENTITY && (gw || gb)) {
     // one pass over both operands gives the weight gradient and the bias gradient of a lifting / projection layer
-    if (in_f <= 4 && thin_linear_ok(in_f, out_f)) return thin_outer(x, gy, gw, 1, gb, nullptr, P, in_f, out_f, ws_slabs, st);
-    if (out_f <= 4 && thin_linear_ok(out_f, in_f)) return thin_outer(gy, x, gw, 0, nullptr, gb, P, out_f, in_f, ws_slabs, st);
+    if (in_f <= 4 && thin_linear_ok(in_f, out_f) && al16(gy)) return thin_outer(x, gy, gw, 1, gb, nullptr, P, in_f, out_f, ws_slabs, st);
+    if (out_f <= 4 && thin_linear_ok(out_f, in_f) && al16(x)) return thin_outer(gy, x, gw, 0, nullptr, gb, P, out_f, in_f, ws_slabs, st);
   }
   if (gw && wgrad_h2_ok(P, out_f, in_f)) {
     RPDE_TRY(wgrad_h2(gy, x, gw, P, in_f, out_f, act_x, ws_slabs, st));
@@ -110,8 +113,8 @@ static inline bool can_fuse_colsum(const float* gy, const float* w, const float*
 static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f,
                              const float* dstored, float* colsum_slab, hipStream_t st, void* wimg = nullptr) {
   if (!dstored && !colsum_slab) {
-    if (out_f <= 4 && thin_linear_ok(out_f, in_f)) return thin_expand(gy, w, 1, in_f, nullptr, gx, P, out_f, in_f, st);
-    if (in_f <= 4 && thin_linear_ok(in_f, out_f)) return thin_contract(gy, w, 1, in_f, nullptr, gx, P, in_f, out_f, st);
+    if (out_f <= 4 && thin_linear_ok(out_f, in_f) && al16(gx)) return thin_expand(gy, w, 1, in_f, nullptr, gx, P, out_f, in_f, st);
+    if (in_f <= 4 && thin_linear_ok(in_f, out_f) && al16(gy)) return thin_contract(gy, w, 1, in_f, nullptr, gx, P, in_f, out_f, st);
   }
   rpde_gemm_desc d = gemm_desc();
   d.A = gy; d.a_kmajor = 1; d.lda = out_f;

@@ -93,11 +93,9 @@ __device__ __forceinline__ f32x4v h2_mfma32(f16x8 ah, f16x8 al, f16x8 bh, f16x8 
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x4v h2_mfma16(f16x4 ah, f16x4 al, f16x4 bh, f16x4 bl, f32x4v c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
-}
+// (There is deliberately no 16-deep variant on v_mfma_f32_16x16x16_f16: on gfx950 / ROCm 7.2 a dependent accumulator chain
+//  that mixed it with the 32-deep form read wrong accumulator registers in the fused synthesis kernel; short reduction
+//  tails are packed into 32-deep fragments instead -- fused_spectral.hip, h2_store_tail.)
 
 // LDS accesses of one wave to its private staging area: the hardware executes a wave's DS instructions in order;
 // this only keeps the compiler from reordering a lane's read above another lane's write

@@ -57,8 +57,13 @@ class GraphedTrainStep:
         torch.cuda.current_stream(x.device).wait_stream(side)
         torch.cuda.synchronize(x.device)
         self.graph = torch.cuda.CUDAGraph()
+        self._captured_hyper = self._hyper()
         with torch.cuda.graph(self.graph):
             self.loss = self._eager()
+
+    def _hyper(self):
+        """learning rate / weight decay reach the optimizer kernel as launch arguments: a replay repeats the captured ones"""
+        return [(float(g.get("lr", 0.0)), float(g.get("weight_decay", 0.0))) for g in self.optimizer.param_groups]
 
     def _eager(self) -> torch.Tensor:
         self.optimizer.zero_grad(set_to_none=False)
@@ -72,6 +77,10 @@ class GraphedTrainStep:
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         if x.shape != self.x.shape or y.shape != self.y.shape:
             raise ValueError(f"GraphedTrainStep was captured for {tuple(self.x.shape)} / {tuple(self.y.shape)}")
+        if self._hyper() != self._captured_hyper:
+            raise RuntimeError(f"GraphedTrainStep: lr / weight_decay changed after capture ({self._captured_hyper} -> "
+                               f"{self._hyper()}); the graph would keep training at the captured values -- build a new "
+                               "GraphedTrainStep (one per learning-rate plateau) or step eagerly")
         self.x.copy_(x, non_blocking=True)
         self.y.copy_(y, non_blocking=True)
         self.graph.replay()

@@ -15,6 +15,9 @@ no moment update, no weight decay, its step count stands still.
 
 ``capturable=True`` keeps the step counter on the device (``rpde_adamw_step_dev``), which lets
 ``rpde.graph.GraphedTrainStep`` capture the step; it requires every parameter to take part in every step.
+Limit: ``lr`` and ``weight_decay`` reach the kernel as launch arguments, so a captured graph replays the values it
+was captured with -- ``GraphedTrainStep`` refuses to replay once a scheduler has changed them (re-capture per
+learning-rate plateau, or step eagerly).
 """
 from __future__ import annotations
 
@@ -67,7 +70,11 @@ class FlatAdamW(torch.optim.Optimizer):
             self.state[p] = {"step": torch.tensor(0.0), "exp_avg": view(self._m), "exp_avg_sq": view(self._v)}
             assert gview.data_ptr() == self.bucket.flat.data_ptr() + 4 * self._offsets[i]
 
-    def zero_grad(self, set_to_none: bool = False) -> None:     # noqa: ARG002 -- the flat buffer is zeroed in place
+    def zero_grad(self, set_to_none: bool = False) -> None:     # noqa: ARG002
+        """Every ``.grad`` becomes None whatever ``set_to_none`` says (``bucket.zero()``): backward then ASSIGNS each
+        parameter's first gradient, and ``gather()`` brings them into the flat buffer.  Code that accumulates into a
+        pre-zeroed ``.grad`` or reads ``p.grad`` right after ``zero_grad()`` sees None, as after torch's default
+        ``zero_grad(set_to_none=True)``."""
         self.bucket.zero()
 
     @torch.no_grad()
@@ -146,11 +153,18 @@ class FlatAdamW(torch.optim.Optimizer):
         for i, p in enumerate(self.bucket.params):
             st = self.state[p]
             m, v = views[id(p)]
+            # torch.optim.AdamW keeps no state for a parameter that never received a gradient (fourier_weight in
+            # mode='low-pass', an unused forecast_ff): such an entry is absent or empty -> fresh moments, step 0
             with torch.no_grad():
-                m.copy_(st["exp_avg"].to(m.device))
-                v.copy_(st["exp_avg_sq"].to(v.device))
+                if "exp_avg" in st and "exp_avg_sq" in st:
+                    m.copy_(st["exp_avg"].to(m.device))
+                    v.copy_(st["exp_avg_sq"].to(v.device))
+                else:
+                    m.zero_()
+                    v.zero_()
             st["exp_avg"], st["exp_avg_sq"] = m, v             # keep the state inside the flat buffers
-            self._steps[i] = int(float(st["step"]))
+            self._steps[i] = int(float(st["step"])) if "step" in st else 0
+            st.setdefault("step", torch.tensor(0.0))
         if self._step_dev is not None:
             self._step_dev.zero_()
             self._step_dev[0] = float(self._steps[0]) if self._steps else 0.0

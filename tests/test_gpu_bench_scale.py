@@ -50,7 +50,9 @@ def test_b32_equals_32_single_sample_calls(gpu_device):
     x = random_fields(B, R, 2, seed=21).to(gpu_device)
     # samples of different magnitude: per-line / per-point scaling must not leak between samples
     x = x * torch.logspace(-2, 2, B, device=gpu_device).view(B, 1, 1, 1)
-    cot = random_fields(B, R, 2, seed=22).to(gpu_device)
+    # (not zero-mean: the bias-like gradients of the last layer are w_out[c] * sum(cot), which a standardised
+    #  cotangent would make pure rounding noise)
+    cot = (random_fields(B, R, 2, seed=22) * 0.7 + 0.4).to(gpu_device)
 
     xb = x.clone().requires_grad_(True)
     out_b = model(xb)
@@ -77,12 +79,11 @@ def test_b32_equals_32_single_sample_calls(gpu_device):
     assert worst_out < 1e-6, worst_out
     assert worst_dx < 1e-6, worst_dx
     names = [n for n, p in model.named_parameters() if p.requires_grad]
-    worst = 0.0
-    for n, g, s in zip(names, gw_b, gw_sum):
-        e = _rel(g, s)
-        worst = max(worst, e)
-        assert e < 2e-5, (n, e)
-    print(f"[b32] worst weight-gradient rel-L2 vs the sum of per-sample gradients {worst:.2e}")
+    errs = {n: _rel(g, s) for n, g, s in zip(names, gw_b, gw_sum)}
+    worst = max(errs, key=errs.get)
+    print(f"[b32] worst weight-gradient rel-L2 vs the sum of per-sample gradients: {worst} {errs[worst]:.2e}")
+    bad = {n: e for n, e in errs.items() if not e < 2e-5}
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("dropout", [0.0, 0.1])

@@ -452,3 +452,47 @@ def test_flat_adamw_refuses_moved_parameters(gpu_device):
     opt2.zero_grad()
     lin2(torch.randn(2, 8, device=gpu_device)).sum().backward()
     opt2.step()
+
+
+def test_flat_adamw_loads_a_torch_state_dict_with_a_never_stepped_parameter(gpu_device):
+    """torch.optim.AdamW keeps no state for a parameter that never received a gradient (fourier_weight in
+    mode='low-pass', an unused forecast_ff): loading such a checkpoint must not raise, and must leave that
+    parameter with fresh moments and step 0"""
+    from rpde.optim import FlatAdamW
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(8, 4, device=gpu_device))
+    b = torch.nn.Parameter(torch.randn(5, device=gpu_device))          # never used
+    ref = torch.optim.AdamW([a, b], lr=1e-2)
+    for _ in range(3):
+        ref.zero_grad()
+        (a.square().sum()).backward()
+        ref.step()
+    sd = ref.state_dict()
+    assert 1 not in sd["state"]                                       # torch has nothing for `b`
+    a2, b2 = torch.nn.Parameter(a.detach().clone()), torch.nn.Parameter(b.detach().clone())
+    opt = FlatAdamW([a2, b2], lr=1e-2)
+    opt.load_state_dict(sd)
+    assert opt._steps == [3, 0]
+    assert float(opt.state[b2]["exp_avg"].abs().max()) == 0.0
+    # one more step on both sides, `b` now in the graph: identical updates
+    for o, (pa, pb) in ((ref, (a, b)), (opt, (a2, b2))):
+        o.zero_grad()
+        (pa.square().sum() + pb.sum()).backward()
+        o.step()
+    assert torch.allclose(a, a2, rtol=1e-6, atol=1e-7) and torch.allclose(b, b2, rtol=1e-6, atol=1e-7)
+
+
+def test_graphed_step_refuses_a_changed_learning_rate(gpu_device):
+    from models.fno import FNO1d
+    from rpde.graph import GraphedTrainStep
+    from rpde.optim import FlatAdamW
+    from utils.loss import RelativeL2Loss
+    torch.manual_seed(0)
+    m = FNO1d(1, 1, modes=8, width=16).to(gpu_device).train()
+    opt = FlatAdamW(m.parameters(), lr=1e-3, capturable=True)
+    x, y = torch.randn(4, 1, 128, device=gpu_device), torch.randn(4, 1, 128, device=gpu_device)
+    step = GraphedTrainStep(m, RelativeL2Loss(), opt, x, y)
+    step(x, y)
+    opt.param_groups[0]["lr"] = 5e-4                                   # what a scheduler does
+    with pytest.raises(RuntimeError, match="changed after capture"):
+        step(x, y)
