@@ -17,6 +17,8 @@
 #include "pointwise.h"
 #include "fused_spectral.h"
 
+#include <stdlib.h>
+
 namespace rpde {
 
 struct Axis {
@@ -171,12 +173,20 @@ static int axis_bwd(const Axis& ax, const float* g, const float* spec_in, const 
 
 // ---- fused 2-D path (fused_spectral.hip): one analysis launch for both axes, mode mix on the small spectra,
 // ---- one synthesis launch that writes the field once
+// RPDE_FUSED_MIX=0: mode mix by pack + GEMM + split per axis (the round-2 sequence; A/B and tests)
+static bool fused_mix_on() {
+  const char* e = getenv("RPDE_FUSED_MIX");
+  return !(e && e[0] == '0');
+}
+
 static size_t fused2d_ws(const Axis& ay, const Axis& ax, int C, bool backward) {
   const size_t spy = arena_bytes(spec_floats(ay, C)), spx = arena_bytes(spec_floats(ax, C));
   const size_t wblk = arena_bytes((size_t)ay.keff * 4 * C * C);
   const size_t img = arena_bytes(fused2d_img_bytes(ay.rows, 2 * ay.kp) / 4) + arena_bytes(fused2d_img_bytes(ax.rows, 2 * ax.kp) / 4);
   const size_t inv = arena_bytes(ay.rows) + arena_bytes(ax.rows);
-  size_t n = wblk + (spy > spx ? spy : spx) + img + inv;
+  // h2 mode mix: weight fragments + per-mode constants + max |spectrum| per line
+  const size_t mix = arena_bytes(mix_wimg_bytes(ay.kp) / 4) + arena_bytes(4 * (size_t)ay.kp) + arena_bytes(ay.rows) + arena_bytes(ax.rows);
+  size_t n = wblk + (spy > spx ? spy : spx) + img + inv + mix;
   if (backward) {
     const int Sy = split_for(ay.rows, wgrad_tiles(C) * ay.keff), Sx = split_for(ax.rows, wgrad_tiles(C) * ax.keff);
     const size_t sl = arena_bytes((size_t)(Sy > Sx ? Sy : Sx) * ay.keff * 4 * C * C);
@@ -187,7 +197,6 @@ static size_t fused2d_ws(const Axis& ay, const Axis& ax, int C, bool backward) {
 
 static int fused2d_fwd(const Axis& ay, const Axis& ax, const float* x, const float* w_y, const float* w_x, float* out,
                        float* spec_y, float* spec_x, int B, int M, int N, int C, int K, int mode, Arena& ar, hipStream_t st) {
-  RPDE_TRY(fused2d_analysis(x, spec_y, spec_x, ay.plan, ax.plan, 0, B, M, N, st));
   float* wblk = ar.take((size_t)ay.keff * 4 * C * C);
   const size_t sy = spec_floats(ay, C), sx = spec_floats(ax, C);
   float* mixed = ar.take(sy > sx ? sy : sx);
@@ -195,7 +204,19 @@ static int fused2d_fwd(const Axis& ay, const Axis& ax, const float* x, const flo
   void* imgx = ar.take(fused2d_img_bytes(ax.rows, 2 * ax.kp) / 4);
   float* invy = ar.take(ay.rows);
   float* invx = ar.take(ax.rows);
+  void* wimg = ar.take(mix_wimg_bytes(ay.kp) / 4);
+  float* wc = ar.take(4 * (size_t)ay.kp);
+  float* amy = ar.take(ay.rows);
+  float* amx = ar.take(ax.rows);
   if (!ar.ok()) { set_error("fspectral2d: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  if (mode == RPDE_MODE_FULL && fused_mix_on()) {
+    // prep (weights -> fragments) | analysis (+ max per line) | mix (spectra -> operand blocks) | synthesis
+    RPDE_TRY(mix_prep(w_y, w_x, K, ay.keff, ay.kp, 0, wimg, wc, st));
+    RPDE_TRY(fused2d_analysis(x, spec_y, spec_x, amy, amx, ay.plan, ax.plan, 0, B, M, N, st));
+    RPDE_TRY(mix_h2(spec_y, spec_x, amy, amx, imgy, imgx, invy, invx, ay.rows, ax.rows, ay.kp, wimg, wc, st));
+    return fused2d_synthesis(imgy, imgx, invy, invx, ay.plan, ax.plan, 0, out, nullptr, B, M, N, st);
+  }
+  RPDE_TRY(fused2d_analysis(x, spec_y, spec_x, nullptr, nullptr, ay.plan, ax.plan, 0, B, M, N, st));
   const Axis* axes[2] = {&ay, &ax};
   const float* ws_[2] = {w_y, w_x};
   float* specs[2] = {spec_y, spec_x};
@@ -229,8 +250,18 @@ static int fused2d_bwd(const Axis& ay, const Axis& ax, const float* g, const flo
   float* invx = ar.take(ax.rows);
   const int Sy = split_for(ay.rows, wgrad_tiles(C) * ay.keff), Sx = split_for(ax.rows, wgrad_tiles(C) * ax.keff);
   float* slabs = ar.take((size_t)(Sy > Sx ? Sy : Sx) * ay.keff * 4 * C * C);
+  void* wimg = ar.take(mix_wimg_bytes(ay.kp) / 4);
+  float* wc = ar.take(4 * (size_t)ay.kp);
+  float* amy = ar.take(ay.rows);
+  float* amx = ar.take(ax.rows);
   if (!ar.ok()) { set_error("fspectral2d: workspace too small"); return RPDE_ERR_WORKSPACE; }
-  RPDE_TRY(fused2d_analysis(g, gsy, gsx, ay.plan, ax.plan, 1, B, M, N, st));
+  const bool hmix = mode == RPDE_MODE_FULL && gx && fused_mix_on();
+  if (hmix) RPDE_TRY(mix_prep(w_y, w_x, K, ay.keff, ay.kp, 1, wimg, wc, st));
+  RPDE_TRY(fused2d_analysis(g, gsy, gsx, hmix ? amy : nullptr, hmix ? amx : nullptr, ay.plan, ax.plan, 1, B, M, N, st));
+  if (hmix) {
+    // d-spectra = g-spectra . W^H, straight into the operand blocks of the adjoint synthesis
+    RPDE_TRY(mix_h2(gsy, gsx, amy, amx, imgy, imgx, invy, invx, ay.rows, ax.rows, ay.kp, wimg, wc, st));
+  }
   const Axis* axes[2] = {&ay, &ax};
   const float* ws_[2] = {w_y, w_x};
   const float* specs[2] = {spec_y, spec_x};
@@ -247,7 +278,7 @@ static int fused2d_bwd(const Axis& ay, const Axis& ax, const float* g, const flo
         RPDE_TRY(mode_mix_wgrad(A, specs[a], gspecs[a], slabs, C, Ss[a], st));
         RPDE_TRY(unpack_mix_grad(slabs, gws[a], C, C, K, A.keff, Ss[a], (long)A.keff * 4 * C * C, st));
       }
-      if (gx) {
+      if (gx && !hmix) {
         RPDE_TRY(pack_mix_weights(ws_[a], wblk, C, C, K, A.keff, st));
         if (A.kp != A.keff) RPDE_HIP(hipMemsetAsync(dsp, 0, spec_floats(A, C) * sizeof(float), st));
         RPDE_TRY(mode_mix(A, gspecs[a], wblk, dsp, C, true, st));
@@ -256,7 +287,7 @@ static int fused2d_bwd(const Axis& ay, const Axis& ax, const float* g, const flo
     } else if (gws[a]) {
       RPDE_HIP(hipMemsetAsync(gws[a], 0, sizeof(float) * 2 * (size_t)C * C * K, st));
     }
-    if (gx) RPDE_TRY(fused2d_split(dspec, imgs[a], invs[a], A.rows, 2 * A.kp, st));
+    if (gx && !hmix) RPDE_TRY(fused2d_split(dspec, imgs[a], invs[a], A.rows, 2 * A.kp, st));
   }
   if (gx) RPDE_TRY(fused2d_synthesis(imgy, imgx, invy, invx, ay.plan, ax.plan, 1, gx, skip, B, M, N, st));
   return RPDE_OK;

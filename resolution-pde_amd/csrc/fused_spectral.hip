@@ -60,8 +60,7 @@ __global__ __launch_bounds__(64) void k_h2_table_ana(const float* __restrict__ s
 // 3 loads per line instead of 6 and 4.  (A 16-deep MFMA for the tail is not an option: mixing
 // v_mfma_f32_16x16x16_f16 and v_mfma_f32_16x16x32_f16 in one dependent chain gave wrong accumulator registers on
 // gfx950 with ROCm 7.2.)
-__host__ __device__ constexpr int h2_np(int TG) { return (3 * TG + 3) / 4; }
-__host__ __device__ constexpr int h2_block_bytes(int K32, int TG) { return (2 * K32 + h2_np(TG)) * 1024; }
+// (h2_np / h2_block_bytes: fused_spectral.h)
 
 // 8 values of group q (rows 32 K32 + 8 q ..) -> the 16-byte pieces of the three slots they occupy
 __device__ __forceinline__ void h2_store_tail(char* __restrict__ blk, int K32, int TG, int q, int c, bool table, const float (&v)[8]) {
@@ -134,6 +133,7 @@ constexpr int ANA_MAXKS = 8;          // n <= 256
 struct AnaAxis {
   const char* timg;   // analysis-type table fragments
   float* spec;        // [lines][R][64]
+  float* amax;        // [lines] max |spectrum| (null: not wanted)
   int n, ks;          // axis length, n / 32
   int lps, rps;       // lines per sample, rounds (of ANA_WAVES lines) per sample
   int zdiv;           // line z -> field offset (z / zdiv) * s1 + (z % zdiv) * s2
@@ -306,6 +306,19 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_h2(const Ana
             for (int nt = 0; nt < 4; ++nt) sp[row * 64 + 16 * nt + li] = tot[mt][nt][j] * inv;
           }
         }
+      if (A.amax) {
+        // (rows beyond R belong to zero table rows: they do not disturb the maximum)
+        float am = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(tot[mt][nt][0]), "v"(tot[mt][nt][1]));
+            asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(tot[mt][nt][2]), "v"(tot[mt][nt][3]));
+          }
+        am = wave_max(am);
+        if (l == 0) A.amax[p.z] = am * inv;
+      }
     }
   };
   float4 ba[8], bb[8];
@@ -319,6 +332,218 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_h2(const Ana
     const Pos pd = next(pc);
     process(bb, pb, pd);
     pa = pc; pb = pd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// analysis of square grids, both axes out of ONE pass over HBM (round 3)
+// ------------------------------------------------------------------------------------------------------------
+// k_dft_analysis_h2 reads the field twice -- once per axis -- and the second read comes from the Infinity Cache at
+// best, which streams no faster than HBM (profiles/r03_mall_bandwidth.txt: 6.1 vs 5.4 TB/s).  An L2 does (12 TB/s),
+// but it holds 4 MB per XCD.  So the two reads of every 32-row block (2 MB at 256^2) are brought together in time and
+// in place: the 32 workgroups of one XCD group (blockIdx % 8; placement is a speed matter only) walk through a sample
+// row block by row block, and in step t
+//   * every wave owns one COLUMN of the sample for the whole sample (256 waves per group = 256 columns) and adds the
+//     32 rows of block t to its x-axis accumulators (one chunk of 32 points, 256 B apart by the row length);
+//   * every workgroup owns one ROW of the block: its eight waves take one 32-point chunk of the row each, and the eight
+//     partial y-axis spectra are summed through LDS (two halves of the channels, 48 KB).
+// Each step reads its 2 MB row block once by rows and once by columns, within microseconds of each other, on one
+// XCD.  No inter-workgroup synchronisation: the workgroups of a group run the same schedule and drift only by
+// scheduling noise.  Needs M = N (one table for both axes) and 32 workgroups per group.
+struct AnaSqP {
+  const float* x; const char* timg;
+  float* spec_y; float* spec_x; float* amax_y; float* amax_x;
+  int B, n, ks, R, ng;
+};
+
+template <int MT>
+__global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const AnaSqP P) {
+  constexpr int TAB = ANA_MAXKS * MT * 2048, STG = ANA_WAVES * 8192, RED = ANA_WAVES * MT * 2 * 1024;
+  __shared__ __attribute__((aligned(16))) char smem[TAB + STG + RED];         // 160 KB at MT = 3: all of it
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, g = l >> 4, li = l & 15;
+  char* const stage = smem + TAB + wave * 8192;
+  // per-wave partial maxima of a row's spectrum: the last 32 bytes of the reduction area (the landing zone of the
+  // partial spectra ends 16 KB before it)
+  float* const wmax = reinterpret_cast<float*>(smem + TAB + STG + RED - 32);
+  const int q = li >> 2, pp = li & 3;
+  const int tsw = ((q >> 1) & 1) | ((g & 1) << 1);
+  const int trow = (8 * g + q) * 128 + pp * 8;
+  typedef s16x4v __attribute__((address_space(3))) * lds_tr;
+
+  const int n = P.n, steps = P.ks;                 // rows per sample = columns = n; row blocks = chunks per row = n / 32
+  const int xg = blockIdx.x % P.ng, jw = blockIdx.x / P.ng, gw = jw * ANA_WAVES + wave;
+  const int nsamp = (P.B - xg + P.ng - 1) / P.ng;
+  const long units = (long)nsamp * steps;           // (sample, row block) pairs of this group, in order
+  const bool has_x = gw < n, has_y = wave < steps;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(P.timg);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = tid; i < steps * MT * 128; i += 64 * ANA_WAVES) dst[i] = src[i];
+    __syncthreads();
+  }
+  const long rowf = (long)n * 64;                   // floats per row of the field
+  auto issue_x = [&](float4 (&buf)[8], long u) {    // column gw, rows of block t: lane (g, li) takes rows 4i + g
+    if (!has_x || u >= units) return;
+    const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
+    const float* q0 = P.x + (((long)(xg + P.ng * sb) * n + 32 * t + g) * n + gw) * 64 + li * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[i] = *reinterpret_cast<const float4*>(q0 + i * 4 * rowf);
+  };
+  auto issue_y = [&](float4 (&buf)[8], long u) {    // row 32 t + jw, points 32 wave ..: lane (g, li) takes points 4i + g
+    if (!has_y || u >= units) return;
+    const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
+    const float* q0 = P.x + (((long)(xg + P.ng * sb) * n + 32 * t + jw) * n + 32 * wave + g) * 64 + li * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[i] = *reinterpret_cast<const float4*>(q0 + i * 256);
+  };
+  // one 32-point chunk into accumulators that stay in scaled units for the whole line (k_dft_analysis_h2's scheme)
+  auto process = [&](float4 (&buf)[8], int s, f32x4v (&tot)[MT][4], int& line_E) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(buf[i].x), "v"(buf[i].y));
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(buf[i].z), "v"(buf[i].w));
+    }
+    m = wave_max(m);
+    {
+      const int E = max((int)(__float_as_uint(m) >> 23) & 0xff, 15 + H2_TABLE_EXP);
+      if (E > line_E) {
+        if (line_E > 0) {
+          const float f = __uint_as_float((unsigned)(127 + line_E - E) << 23);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) tot[mt][nt][j] *= (E - line_E < 126 ? f : 0.f);
+        }
+        line_E = E;
+      }
+    }
+    const float scale = __uint_as_float((unsigned)(268 - line_E) << 23);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint2 hi, lo;
+      h2_split4(buf[i].x * scale, buf[i].y * scale, buf[i].z * scale, buf[i].w * scale, hi, lo);
+      const int off = stage_off(4 * i + g, li);
+      *reinterpret_cast<uint2*>(stage + off) = hi;
+      *reinterpret_cast<uint2*>(stage + 4096 + off) = lo;
+    }
+  };
+  auto mfma_chunk = [&](int s, f32x4v (&tot)[MT][4]) {
+    wave_lds_fence();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const char* t = stage + trow + ((nt ^ tsw) << 5);
+      union { struct { s16x4v a, b; } h; f16x8 v; } bh, bl;
+      bh.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t));
+      bh.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 512));
+      bl.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 4096));
+      bl.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 4096 + 512));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const char* ta = smem + (s * MT + mt) * 2048 + l * 16;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(ta), al = *reinterpret_cast<const f16x8*>(ta + 1024);
+        tot[mt][nt] = h2_mfma32(ah, al, bh.v, bl.v, tot[mt][nt]);
+      }
+    }
+    wave_lds_fence();
+  };
+
+  f32x4v totx[MT][4], toty[MT][4];
+  int Ex = 0;
+  float4 bx[8], by[8];
+  issue_x(bx, 0);
+  issue_y(by, 0);
+  for (long u = 0; u < units; ++u) {
+    const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
+    const int b = xg + P.ng * sb;
+    // ---- x axis: this wave's column, rows of block t ----
+    if (has_x) {
+      if (t == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) totx[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        Ex = 0;
+      }
+      process(bx, t, totx, Ex);
+      issue_x(bx, u + 1);
+      mfma_chunk(t, totx);
+      if (t == steps - 1) {
+        const long z = (long)b * n + gw;
+        float* __restrict__ sp = P.spec_x + z * (long)P.R * 64;
+        const float inv = __uint_as_float((unsigned)(Ex - 14 - H2_TABLE_EXP) << 23);
+        float am = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = 16 * mt + 4 * g + j;
+            if (row < P.R) {
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) sp[row * 64 + 16 * nt + li] = totx[mt][nt][j] * inv;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) am = fmaxf(am, fabsf(totx[mt][nt][j]));
+          }
+        am = wave_max(am);
+        if (l == 0 && P.amax_x) P.amax_x[z] = am * inv;
+      }
+    }
+    // ---- y axis: row 32 t + jw of the block; this wave's chunk of it, then the sum over the chunks ----
+    float invy = 0.f;
+    if (has_y) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) toty[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+      int Ey = 0;
+      process(by, wave, toty, Ey);
+      issue_y(by, u + 1);
+      mfma_chunk(wave, toty);
+      invy = __uint_as_float((unsigned)(Ey - 14 - H2_TABLE_EXP) << 23);
+    }
+    const long zy = (long)b * n + 32 * t + jw;
+    float* __restrict__ spy = P.spec_y + zy * (long)P.R * 64;
+    // the eight partial spectra of the row -> one: every wave is done with its staging area until the next step, so the
+    // staging areas + the reduction area together take all partials at once ([wave][mt][nt][lane] float4, 4 MT KB per
+    // wave), one pass, two barriers
+    char* const land = smem + TAB;                  // STG + RED = 112 KB >= 8 waves x 12 KB
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everyone's chunks are out of the staging areas
+    if (has_y) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f32x4v v = toty[mt][nt];
+          *reinterpret_cast<float4*>(land + ((wave * MT + mt) * 4 + nt) * 1024 + l * 16) =
+              make_float4(v[0] * invy, v[1] * invy, v[2] * invy, v[3] * invy);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float am = 0.f;
+    for (int e = tid; e < MT * 4 * 64; e += 64 * ANA_WAVES) {
+      const int mt = e >> 8, nt = (e >> 6) & 3, ln = e & 63;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int w2 = 0; w2 < steps; ++w2) {
+        const float4 v = *reinterpret_cast<const float4*>(land + ((w2 * MT + mt) * 4 + nt) * 1024 + ln * 16);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      const int row0 = 16 * mt + 4 * (ln >> 4), ch = 16 * nt + (ln & 15);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (row0 + j < P.R) { spy[(row0 + j) * 64 + ch] = av[j]; am = fmaxf(am, fabsf(av[j])); }
+    }
+    am = wave_max(am);
+    if (l == 0) wmax[wave] = am;                                           // (its own 32 bytes behind the landing zone)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the landing zone has been read: staging may be reused
+    if (tid == 0 && P.amax_y) {
+      float a8 = 0.f;
+      for (int i = 0; i < ANA_WAVES; ++i) a8 = fmaxf(a8, wmax[i]);
+      P.amax_y[zy] = a8;
+    }
   }
 }
 
@@ -365,6 +590,12 @@ __global__ __launch_bounds__(256) void k_spec_split_h2(const float* __restrict__
     } else if (g < TG) {
       h2_store_tail(blk, K32, TG, g, li, false, v[s]);
     }
+  }
+  // slots of the packed fragments that no group uses: zero (k_dft_synthesis3_h2 feeds whole fragments to the MFMAs)
+  if (TG > 0 && g == 0) {
+#pragma unroll
+    for (int slot = 3 * TG; slot < 4 * h2_np(TG); ++slot)
+      *reinterpret_cast<uint4*>(blk + (2 * K32 + slot / 4) * 1024 + ((slot & 3) * 16 + li) * 16) = make_uint4(0, 0, 0, 0);
   }
 }
 
@@ -519,6 +750,370 @@ __global__ __launch_bounds__(256, 2) void k_dft_synthesis2_h2(const SynP P) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// synthesis of both axes, 64 x 64 point tiles (round 3)
+// ------------------------------------------------------------------------------------------------------------
+// k_dft_synthesis2_h2 gives every wave a 16 x 16 x 16-channel tile and lets it fetch its 32 spectrum lines itself:
+// 5.5 bytes loaded from L2 per byte stored (3.2 GB per forward at 256^2, B = 32), and that -- not HBM -- bounded it
+// (317 us).  Here an 8-wave workgroup owns 64 x 64 points x 16 channels, so a line's fragments are fetched from L2 once
+// per FOUR 16-point tiles: 1.5 bytes per byte stored.
+//   * the 64 x-lines (columns) and 64 y-lines (rows) of the tile stream through a 3-slot LDS ring in 8 stages of 16
+//     lines, by LDS-DMA (global_load_lds: 1 KB fragment pieces land lane-linear, exactly as the MFMA wants them; no
+//     registers held), two stages ahead; one s_barrier per stage.  The table blocks and the line scales travel the
+//     same way (a 12 KB corner of LDS that holds the x-axis table during the x phase and the y-axis table after it):
+//     no ordinary global load anywhere in the kernel, so the compiler never drains the DMA queue for one.
+//   * wave (mt, p) owns the 16-row block mt and the two 16-column blocks p, p + 2: 128 accumulator registers.  Stages
+//     0-3 form the x-axis part column by column (accumulator rows = m), stages 4-7 the y-axis part row by row
+//     (accumulator rows = n).  Between them the x part is turned into the y layout INSIDE the register file: both
+//     layouts keep the channel on lane & 15, so the turn is sixteen 4 x 4 transposes between the register index and
+//     the lane-row index -- two v_permlane32_swap + two v_permlane16_swap each.  No LDS turning buffer (the old kernel
+//     spent ~200 LDS instructions and 2.1 M bank-conflict cycles per launch there).
+//   * persistent: one workgroup per CU walks over its share of the tiles, and the ring never runs dry -- the first two
+//     stages (and the tables) of the NEXT tile are requested during the last stages of the current one.  In-kernel
+//     stamps of the first, one-tile-per-workgroup version: 33 % of a workgroup's life was the cold start of its DMA
+//     queue, 29 % the burst of stores at its end.
+//   * forward: the stores of a tile are spread over eight stages, four 16-byte stores per wave and stage (a 4 x 4
+//     transpose inside each quad of lanes gives every lane four consecutive channels of one point); column block 1 of
+//     a tile leaves during the x stages of the next tile.  Adjoint with a skip gradient: loads + stores in four batches
+//     after the last stage.
+//   * what bounds it now (measured with the parts switched off one at a time, 256^2, B = 32): DMA skeleton alone 76 us,
+//     + MFMAs 25 us, + stores 130 us; HBM traffic 0.30 GB read + 0.54 GB written in 215-230 us.  Burst or spread, in step
+//     or staggered across XCDs, 4-byte or 16-byte stores: the store time adds to the rest (a CU's memory pipeline
+//     takes a 16-segment store instruction in ~60-90 cycles and DMA pieces through the same queue).
+//   * every line carries its own power-of-two scale (undone on the accumulators, as before).
+constexpr int SYN3_WAVES = 8;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// a and b hold one value per lane; afterwards a's upper half (lane-rows 2, 3) and b's lower half (rows 0, 1) have changed
+// places / a's odd lane-rows and b's even lane-rows have changed places
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void swap_rows(float& a, float& b) {
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x); b = __uint_as_float(r.y);
+}
+
+// 4 x 4 transpose inside every quad of lanes: afterwards register c of lane p (p = lane & 3) holds what register p of
+// lane c held.  Two butterfly stages on DPP quad permutes (lane ^ 1, then lane ^ 2).
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3) {
+  const bool b0 = threadIdx.x & 1, b1 = threadIdx.x & 2;
+  { const float a = quad_dpp<0xB1>(v0), c = quad_dpp<0xB1>(v1); v1 = b0 ? v1 : a; v0 = b0 ? c : v0; }   // quad_perm [1,0,3,2]
+  { const float a = quad_dpp<0xB1>(v2), c = quad_dpp<0xB1>(v3); v3 = b0 ? v3 : a; v2 = b0 ? c : v2; }
+  { const float a = quad_dpp<0x4E>(v0), c = quad_dpp<0x4E>(v2); v2 = b1 ? v2 : a; v0 = b1 ? c : v0; }   // quad_perm [2,3,0,1]
+  { const float a = quad_dpp<0x4E>(v1), c = quad_dpp<0x4E>(v3); v3 = b1 ? v3 : a; v1 = b1 ? c : v1; }
+}
+
+// makes the compiler produce x here, in program order relative to the other volatile asm statements (barriers, waits):
+// without it the VALU work between the two phases (scaling, turn, the y phase's multiply-adds) is sunk to the end of
+// the kernel and both phases' 128 accumulators are alive at once (80 spilled registers)
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+
+// one tile of one channel block of one sample
+struct Syn3Item {
+  const char* gx; const char* gy;       // fragment pieces of the tile's first column / first row (this channel block)
+  const char* tx; const char* ty;       // table blocks of the tile's first 16 rows / first 16 columns
+  const float* ivx; const float* ivy;   // line scales of the tile's columns / rows
+  long o;                               // float offset of the tile's first point, first channel of the block
+};
+
+template <int K32, int TG, bool SKIP>
+__global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const SynP P) {
+  constexpr int NP = h2_np(TG), NF = 2 * K32 + NP;
+  constexpr int BB = NF * 1024;
+  constexpr long LB = 4L * BB;
+  constexpr int SLOT = 16 * BB;                 // one stage: 16 lines
+  static_assert(NF <= 3, "ring of three 16-line slots + the table corner must fit 160 KB");
+  constexpr int TAB = 3 * SLOT, INV = TAB + 4 * BB, LDS_BYTES = INV + 512;
+  constexpr int NST = SKIP ? 0 : 8;             // stores a wave issues at the end of a y stage
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = l >> 4, li = l & 15;
+  const int mt = w & 3, p = w >> 2;
+  const unsigned lane16 = l * 16;
+  typedef Frag<K32, TG> F;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+  // ---- this workgroup's tiles.  Blocks b, b + 8, .. share an XCD (an L2): group x = blockIdx & 7 takes the samples
+  // x, x + 8, .., tile by tile, the four channel blocks of a tile next to each other (their 64-byte pieces complete each
+  // other's 256-byte lines in L2); its workgroups take the tiles round-robin, so the ~32 in flight are neighbours that
+  // share spectrum lines.  (Placement is a speed matter only.)
+  const int tn = P.N >> 6, wps = (P.M >> 6) * tn * 4;
+  const int ng = P.sy;            // groups: 8, or the batch size when that is smaller
+  const int xg = blockIdx.x % ng, jw = blockIdx.x / ng, nj = gridDim.x / ng;
+  const int nsamp = (P.B - xg + ng - 1) / ng;
+  const long nitems = (long)nsamp * wps;
+  auto item_at = [&](long q) {
+    Syn3Item it;
+    const int sb = (int)(q / wps), t = (int)(q - (long)sb * wps);
+    const int b = xg + ng * sb, cb = t & 3, tile = t >> 2;
+    const int m0 = (tile / tn) << 6, n0 = (tile % tn) << 6;
+    it.gx = P.imgx + ((long)b * P.N + n0) * LB + cb * BB;
+    it.gy = P.imgy + ((long)b * P.M + m0) * LB + cb * BB;
+    it.tx = P.tabx + (long)(m0 >> 4) * BB;
+    it.ty = P.taby + (long)(n0 >> 4) * BB;
+    it.ivx = P.invx + (long)b * P.N + n0;
+    it.ivy = P.invy + (long)b * P.M + m0;
+    it.o = (((long)b * P.M + m0) * P.N + n0) * 64 + 16 * cb;
+    return it;
+  };
+  long q = jw;
+  if (q >= nitems) return;
+  Syn3Item cur = item_at(q);
+
+  // ---- DMA ----
+  // piece i (of 2 NF) of this wave for stage s of a tile: stage s < 4: columns 8 (s & 1) .. + 7 of the column blocks
+  // (s >> 1) * 2 + {0, 1}; stage s >= 4: rows 4 (s - 4) .. + 3 of the four row blocks
+  auto issue_piece = [&](const Syn3Item& it, int s, int i, int slot) {
+    const int idx = w + 8 * i, ell = idx / NF, f = idx - ell * NF;     // (ell * NF + f == idx: pieces land in order)
+    const char* src;
+    if (s < 4) src = it.gx + (long)(16 * ((ell >> 3) + 2 * (s >> 1)) + 8 * (s & 1) + (ell & 7)) * LB + f * 1024;
+    else src = it.gy + (long)(16 * (ell >> 2) + 4 * (s - 4) + (ell & 3)) * LB + f * 1024;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + lane16), (lds_ptr)(smem + slot * SLOT + idx * 1024), 16, 0, 0);
+  };
+  // the four 16-row blocks of a table (x axis: rows m0 .. m0 + 63; y axis: the column blocks p + 2a at [p * 2 + a])
+  auto issue_table = [&](const char* tab, bool yaxis) {
+#pragma unroll
+    for (int i = 0; i < (4 * NF + 7) / 8; ++i) {
+      const int idx = w + 8 * i;
+      if (idx < 4 * NF) {
+        const int blk = idx / NF, f = idx - blk * NF;
+        const int src_blk = yaxis ? (blk >> 1) + 2 * (blk & 1) : blk;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(tab + (long)src_blk * BB + f * 1024 + lane16), (lds_ptr)(smem + TAB + idx * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto issue_inv = [&](const Syn3Item& it) {          // 64 + 64 floats, one 4-byte DMA each
+    if (w == 6) __builtin_amdgcn_global_load_lds((glb_ptr)(it.ivx + l), (lds_ptr)(smem + INV), 4, 0, 0);
+    if (w == 7) __builtin_amdgcn_global_load_lds((glb_ptr)(it.ivy + l), (lds_ptr)(smem + INV + 256), 4, 0, 0);
+  };
+
+  auto lds_frag = [&](F& f, const char* base) {
+#pragma unroll
+    for (int s2 = 0; s2 < K32; ++s2) {
+      f.h[s2] = *reinterpret_cast<const f16x8*>(base + s2 * 1024);
+      f.lo[s2] = *reinterpret_cast<const f16x8*>(base + (K32 + s2) * 1024);
+    }
+#pragma unroll
+    for (int qq = 0; qq < NP; ++qq) f.pk[qq] = *reinterpret_cast<const f16x8*>(base + (2 * K32 + qq) * 1024);
+  };
+  auto chain = [&](const F& tab, const F& f) {
+    f32x4v c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qq = 0; qq < NP; ++qq) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab.pk[qq], f.pk[qq], c, 0, 0, 0);
+#pragma unroll
+    for (int s2 = K32 - 1; s2 >= 0; --s2) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab.lo[s2], f.h[s2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab.h[s2], f.lo[s2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab.h[s2], f.h[s2], c, 0, 0, 0);
+    }
+    return c;
+  };
+
+  // ---- prologue: tables / scales of the first tile, then its first two stages ----
+  issue_table(cur.tx, false);
+  issue_inv(cur);
+#pragma unroll
+  for (int i = 0; i < 2 * NF; ++i) issue_piece(cur, 0, i, 0);
+#pragma unroll
+  for (int i = 0; i < 2 * NF; ++i) issue_piece(cur, 1, i, 1);
+  int ring = 0;                 // slot of the current tile's stage 0
+  bool first = true;
+  const int qd = li >> 2, pl = li & 3;
+  // acc[a][i][jj]: x phase -- column i of column block a, rows m = 4g + jj; after the turn, physical register
+  // [a][4 (r >> 2) + j][r & 3] holds row r, column 4g + j.  Lives across tiles: column block 1 of a finished tile is
+  // stored while the x stages of the next tile refill column block 0 (below).
+  float acc[2][16][4];
+  long o_prev = 0;
+
+  while (true) {
+    const long qn = q + nj;
+    const bool has_next = qn < nitems;
+    Syn3Item nxt = cur;
+    if (has_next) nxt = item_at(qn);
+    F tx, ty[2];
+    // line fragments are read one line ahead of their MFMAs, no further (the compiler barrier keeps the LDS reads of
+    // later lines from being hoisted on top of 128 live accumulators)
+    F fq[2];
+    float invx_l[2], invy_l;
+    // output: after the quad transpose lane (g, 4 qd + pl) holds channels 4 qd .. + 3 of the point (row r, column
+    // 16 (p + 2a) + 4g + pl)
+    const long o = cur.o + ((long)(16 * mt) * P.N + 16 * p + 4 * g + pl) * 64 + 4 * qd;
+    auto tile_out = [&](int r, int a) {
+      float4 v = make_float4(acc[a][4 * (r >> 2) + 0][r & 3], acc[a][4 * (r >> 2) + 1][r & 3], acc[a][4 * (r >> 2) + 2][r & 3],
+                             acc[a][4 * (r >> 2) + 3][r & 3]);
+      quad_transpose(v.x, v.y, v.z, v.w);
+      return v;
+    };
+    // forward: the stores of a tile are spread evenly over EIGHT stages, four per wave and stage -- a CU's store path
+    // takes ~60-90 cycles per 16-segment store instruction, so the 256 KB of a tile need about as long as all its other
+    // work, and issued in one burst (at the end of the tile, or over its four y stages) they simply added their time
+    // to it (measured: 139 of 229 us).  Rows 4k .. 4k + 3 of column block 0 leave at the end of y stage k (they are
+    // final then), rows 4k .. 4k + 3 of column block 1 at the START of x stage k of the NEXT tile: x stage s refills
+    // the registers of rows 8 (s & 1) .. + 7 of column block s >> 1, so block 0 is free when the next tile begins and
+    // every row group of block 1 has left before its registers are written again.
+    auto store_rows = [&](long obase, int k, int a) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * k + rr;
+        *reinterpret_cast<float4*>(P.out + obase + ((long)r * P.N + 32 * a) * 64) = tile_out(r, a);
+      }
+    };
+#ifdef RPDE_STAMPS
+    const bool stamp_on = l == 0 && w == 5 && blockIdx.x >= 96 && blockIdx.x < 160 && q == jw + 2 * (long)nj;
+    const int stamp_slot = (int)blockIdx.x - 96;
+#endif
+    FSTAMP(1, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      // ---- this wave's pieces of stage s have landed.  vmcnt(N): everything but the N youngest operations of this wave
+      // is done; younger than the pieces of stage s are the pieces of stage s + 1 (2 NF) and the stores of the y stages
+      // in between (NST each); a wait that also covers table / scale pieces issued in between only over-waits
+      // (forward: + the stores in between: 4 at the end of every y stage, 4 at the start of every x stage but the first tile's)
+      constexpr int Q = SKIP ? 0 : 4;
+      if (SKIP && !first && s < 2) wait_vmcnt<63>();                       // (behind the 64 loads / stores of the epilogue)
+      else if (first && s < 5) wait_vmcnt<2 * NF>();
+      else if (s == 0 || s == 1 || s == 6) wait_vmcnt<2 * NF + 2 * Q>();
+      else if (s <= 5) wait_vmcnt<2 * NF + Q>();
+      else { if (has_next) wait_vmcnt<2 * NF + 2 * Q>(); else wait_vmcnt<2 * Q>(); }
+      FSTAMP(1, 1 + 3 * s);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's have; everyone is done with stage s - 1
+      FSTAMP(1, 2 + 3 * s);
+      const int slot_s = (ring + s) % 3, slot_n = (ring + s + 2) % 3;
+      // what this stage requests (spread between its MFMA chains): stage s + 2 of this tile, or stage s - 6 of the next
+      auto request = [&](int i) {
+        if (i >= 2 * NF) return;
+        if (s + 2 < 8) issue_piece(cur, s + 2, i, slot_n);
+        else if (has_next) issue_piece(nxt, s - 6, i, slot_n);
+      };
+      // tables: the y-axis blocks replace the x-axis blocks once every wave has its x block in registers (stage 0); the
+      // next tile's x blocks and scales replace them once every wave has its y blocks (stage 4)
+      if (!SKIP && s < 4 && !first) store_rows(o_prev, s, 1);
+      if (s == 1) issue_table(cur.ty, true);
+      if (s == 5 && has_next) { issue_table(nxt.tx, false); issue_inv(nxt); }
+      const char* slot = smem + slot_s * SLOT + l * 16;
+      if (s < 4) {
+        const int a = s >> 1, h = s & 1;
+        if (s == 0) {
+          lds_frag(tx, smem + TAB + mt * BB + l * 16);
+          invx_l[0] = *reinterpret_cast<const float*>(smem + INV + (16 * p + li) * 4);
+          invx_l[1] = *reinterpret_cast<const float*>(smem + INV + (16 * (p + 2) + li) * 4);
+          invy_l = *reinterpret_cast<const float*>(smem + INV + 256 + (16 * mt + li) * 4);
+        }
+        lds_frag(fq[0], slot + (p * 8) * BB);
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+          if (c8 + 1 < 8) lds_frag(fq[(c8 + 1) & 1], slot + (p * 8 + c8 + 1) * BB);
+          asm volatile("" ::: "memory");
+          const f32x4v c = chain(tx, fq[c8 & 1]);
+          request(c8);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[a][8 * h + c8][jj] = c[jj];
+        }
+        if (s == 3) {
+          // ---- x part -> true units, then turned into the y layout ----
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(invx_l[a2]), i));
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) acc[a2][i][jj] *= sc;
+            }
+#pragma unroll
+            for (int jy = 0; jy < 4; ++jy)
+#pragma unroll
+              for (int jr = 0; jr < 4; ++jr) {
+                swap_halves(acc[a2][jy][jr], acc[a2][8 + jy][jr]);
+                swap_halves(acc[a2][4 + jy][jr], acc[a2][12 + jy][jr]);
+                swap_rows(acc[a2][jy][jr], acc[a2][4 + jy][jr]);
+                swap_rows(acc[a2][8 + jy][jr], acc[a2][12 + jy][jr]);
+              }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) pin(acc[a2][i][jj]);
+          }
+        }
+      } else {
+        const int sy = s - 4;
+        if (sy == 0) {
+          lds_frag(ty[0], smem + TAB + ((p * 2 + 0) * NF) * 1024 + l * 16);
+          lds_frag(ty[1], smem + TAB + ((p * 2 + 1) * NF) * 1024 + l * 16);
+        }
+        lds_frag(fq[0], slot + (mt * 4) * BB);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = 4 * sy + rr;
+          if (rr + 1 < 4) lds_frag(fq[(rr + 1) & 1], slot + (mt * 4 + rr + 1) * BB);
+          asm volatile("" ::: "memory");
+          const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(invy_l), r));
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const f32x4v c = chain(ty[a], fq[rr & 1]);
+            request(2 * rr + a);                                  // (2 NF <= 6 pieces: all out before the stage's stores)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[a][4 * (r >> 2) + j][r & 3] = fmaf(c[j], sc, acc[a][4 * (r >> 2) + j][r & 3]);
+              pin(acc[a][4 * (r >> 2) + j][r & 3]);
+            }
+          }
+        }
+        if (!SKIP) store_rows(o, sy, 0);
+      }
+      FSTAMP(1, 3 + 3 * s);
+    }
+    if (SKIP) {
+      // the tensor added to the result (the gradient that arrives through the skip connection) is fetched in four
+      // batches of 8 float4, each batch a step ahead of the additions and stores it feeds: loads and stores share
+      // one in-order counter, so load - add - store per element would wait for every store before the next load
+      float4 sk[2][8];
+      auto fetch = [&](float4 (&d)[8], int k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = *reinterpret_cast<const float4*>(P.skip + o + ((long)(4 * k + (e >> 1)) * P.N + 32 * (e & 1)) * 64);
+      };
+      fetch(sk[0], 0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k + 1 < 4) fetch(sk[(k + 1) & 1], k + 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = 4 * k + (e >> 1), a = e & 1;
+          float4 v = tile_out(r, a);
+          const float4 q4 = sk[k & 1][e];
+          v.x += q4.x; v.y += q4.y; v.z += q4.z; v.w += q4.w;
+          *reinterpret_cast<float4*>(P.out + o + ((long)r * P.N + 32 * a) * 64) = v;
+        }
+      }
+    }
+    FSTAMP(1, 26);
+    if (!has_next) {
+      if (!SKIP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store_rows(o, k, 1);        // the last tile's column block 1
+      }
+      break;
+    }
+    o_prev = o;
+    cur = nxt;
+    q = qn;
+    ring = (ring + 8) % 3;
+    first = false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 bool fused2d_ok(int M, int N, int C, int keff_y, int keff_x) {
@@ -542,8 +1137,31 @@ size_t fused2d_img_bytes(long lines, int R) { return (size_t)lines * 4 * h2_bloc
     }                                                                                           \
   } while (0)
 
-int fused2d_analysis(const float* x, float* spec_y, float* spec_x, const rpde_plan* py, const rpde_plan* px, int adjoint,
-                     int B, int M, int N, hipStream_t st) {
+// RPDE_ANA_SQ=0: keep the two-read analysis kernel for every shape (A/B, tests)
+static bool ana_sq_ok(int M, int N, int cus) {
+  if (const char* e = getenv("RPDE_ANA_SQ")) if (e[0] == '0') return false;
+  return M == N && cus >= 256;
+}
+
+int fused2d_analysis(const float* x, float* spec_y, float* spec_x, float* amax_y, float* amax_x, const rpde_plan* py,
+                     const rpde_plan* px, int adjoint, int B, int M, int N, hipStream_t st) {
+  {
+    int dev = 0, cus = 256;
+    RPDE_HIP(hipGetDevice(&dev));
+    RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (ana_sq_ok(M, N, cus) && py->h2_ana[adjoint] == px->h2_ana[adjoint]) {
+      AnaSqP Q;
+      Q.x = x; Q.timg = (const char*)py->h2_ana[adjoint]; Q.spec_y = spec_y; Q.spec_x = spec_x; Q.amax_y = amax_y; Q.amax_x = amax_x;
+      Q.B = B; Q.n = N; Q.ks = N / 32; Q.R = 2 * py->kp; Q.ng = B < 8 ? B : 8;
+      const dim3 grid(32 * Q.ng), blk(64 * ANA_WAVES);
+      const int MTq = (Q.R + 15) / 16;
+      if (MTq == 1) hipLaunchKernelGGL(k_dft_analysis_sq_h2<1>, grid, blk, 0, st, Q);
+      else if (MTq == 2) hipLaunchKernelGGL(k_dft_analysis_sq_h2<2>, grid, blk, 0, st, Q);
+      else hipLaunchKernelGGL(k_dft_analysis_sq_h2<3>, grid, blk, 0, st, Q);
+      RPDE_LAUNCH_CHECK();
+      return RPDE_OK;
+    }
+  }
   AnaP P;
   memset(&P, 0, sizeof(P));
   P.x = x; P.naxes = 2; P.B = B; P.R = 2 * py->kp;
@@ -553,10 +1171,10 @@ int fused2d_analysis(const float* x, float* spec_y, float* spec_x, const rpde_pl
   long ch = (64L << 20) / sample_bytes;
   P.chunk = (int)(ch < 1 ? 1 : (ch > B ? B : ch));
   AnaAxis& ay = P.ax[0];
-  ay.timg = (const char*)py->h2_ana[adjoint]; ay.spec = spec_y; ay.n = N; ay.ks = N / 32; ay.lps = M;
+  ay.timg = (const char*)py->h2_ana[adjoint]; ay.spec = spec_y; ay.amax = amax_y; ay.n = N; ay.ks = N / 32; ay.lps = M;
   ay.rps = (M + ANA_WAVES - 1) / ANA_WAVES; ay.zdiv = 1; ay.s1 = (long)N * 64; ay.s2 = 0; ay.ldk = 64;
   AnaAxis& ax = P.ax[1];
-  ax.timg = (const char*)px->h2_ana[adjoint]; ax.spec = spec_x; ax.n = M; ax.ks = M / 32; ax.lps = N;
+  ax.timg = (const char*)px->h2_ana[adjoint]; ax.spec = spec_x; ax.amax = amax_x; ax.n = M; ax.ks = M / 32; ax.lps = N;
   ax.rps = (N + ANA_WAVES - 1) / ANA_WAVES; ax.zdiv = N; ax.s1 = (long)M * N * 64; ax.s2 = 64; ax.ldk = (long)N * 64;
   P.items = ((B + P.chunk - 1) / P.chunk) * P.chunk * (ay.rps + ax.rps);
   // one persistent workgroup per CU (the table + 8 staging areas take 80-112 KB of LDS)
@@ -579,12 +1197,51 @@ int fused2d_split(const float* spec, void* img, float* inv, long lines, int R, h
   return RPDE_OK;
 }
 
+// RPDE_SYN3=0: keep the 16 x 16 tile kernel for every shape (A/B, tests)
+static bool syn3_ok(int M, int N) {
+  if (const char* e = getenv("RPDE_SYN3")) if (e[0] == '0') return false;
+  return M % 64 == 0 && N % 64 == 0;
+}
+
 int fused2d_synthesis(const void* imgy, const void* imgx, const float* invy, const float* invx, const rpde_plan* py,
                       const rpde_plan* px, int adjoint, float* out, const float* skip, int B, int M, int N, hipStream_t st) {
   SynP P;
   P.imgy = (const char*)imgy; P.imgx = (const char*)imgx; P.invy = invy; P.invx = invx;
   P.taby = (const char*)py->h2_syn[adjoint]; P.tabx = (const char*)px->h2_syn[adjoint];
   P.out = out; P.skip = skip; P.B = B; P.M = M; P.N = N;
+  const int R3 = 2 * py->kp;
+  const int NF3 = 2 * (R3 / 32) + (3 * ((R3 % 32) / 8) + 3) / 4;
+  if (syn3_ok(M, N) && NF3 <= 3) {
+    int dev = 0, cus = 256;
+    RPDE_HIP(hipGetDevice(&dev));
+    RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // persistent: one workgroup per CU, in 8 groups (one per XCD; fewer when the batch is smaller); never more per group
+    // than the busiest group has tiles
+    const int ng = B < 8 ? B : 8;
+    P.sy = ng;
+    P.sx = 1;
+    const long wps = (long)(M / 64) * (N / 64) * 4;
+    long per_group = cus / ng;
+    const long most = (long)((B + ng - 1) / ng) * wps;
+    if (per_group > most) per_group = most;
+    if (per_group < 1) per_group = 1;
+    const dim3 grid3((unsigned)(ng * per_group)), blk3(64 * SYN3_WAVES);
+#define RPDE_SYN3_LAUNCH(K32_, TG_)                                                                                     \
+    do {                                                                                                                \
+      if (skip) hipLaunchKernelGGL((k_dft_synthesis3_h2<K32_, TG_, true>), grid3, blk3, 0, st, P);                      \
+      else hipLaunchKernelGGL((k_dft_synthesis3_h2<K32_, TG_, false>), grid3, blk3, 0, st, P);                          \
+    } while (0)
+    switch (R3 / 8) {
+      case 1: RPDE_SYN3_LAUNCH(0, 1); break;
+      case 2: RPDE_SYN3_LAUNCH(0, 2); break;
+      case 3: RPDE_SYN3_LAUNCH(0, 3); break;
+      case 4: RPDE_SYN3_LAUNCH(1, 0); break;
+      default: RPDE_SYN3_LAUNCH(1, 1); break;
+    }
+#undef RPDE_SYN3_LAUNCH
+    RPDE_LAUNCH_CHECK();
+    return RPDE_OK;
+  }
   // (super-tile side, measured at B = 32, 256^2, forward + backward: 2 -> 1.52 ms, 4 -> 1.44, 8 -> 1.45, 16 -> 1.53)
   auto side = [](int tiles) { int s = tiles < 8 ? tiles : 8; while (tiles % s) --s; return s; };
   P.sy = side(M / 16); P.sx = side(N / 16);
