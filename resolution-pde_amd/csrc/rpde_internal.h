@@ -74,6 +74,9 @@ __device__ __forceinline__ float dgelu_f(float u) {
 }
 // h = act(u), d = act'(u) in one evaluation
 __device__ __forceinline__ void act_both(int act, float u, float& h, float& d) {
+#ifdef RPDE_EXP_NOACT      // timing experiment (profiles/ff_bench.py): what the fused kernels would cost with a free activation
+  h = u; d = 1.f; return;
+#endif
   if (act == RPDE_ACT_GELU) {
     float c, gk;
     phi_parts(u, c, gk);

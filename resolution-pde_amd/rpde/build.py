@@ -47,14 +47,18 @@ def _newest_header() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, stamps: bool = False, define: str = "") -> str:
     """stamps=True: debug variant with in-kernel phase timestamps (RPDE_STAMPS) -> lib/librpde_hip_stamps.so,
-    loaded instead of the product library when RPDE_LIB points at it (profiles/stamps.py)."""
+    loaded instead of the product library when RPDE_LIB points at it (profiles/stamps.py).
+    define="X": experiment variant compiled with -DX -> lib/librpde_hip_X.so (same mechanism; profiles/ff_bench.py)."""
     global OBJDIR, LIB
     if stamps:
         OBJDIR, LIB = os.path.join(REPO, "build", "rpde_stamps"), os.path.join(LIBDIR, "librpde_hip_stamps.so")
         if "-DRPDE_STAMPS" not in FLAGS:
             FLAGS.append("-DRPDE_STAMPS")
+    elif define:
+        OBJDIR, LIB = os.path.join(REPO, "build", "rpde_" + define), os.path.join(LIBDIR, f"librpde_hip_{define}.so")
+        FLAGS.append("-D" + define)
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hdr = _newest_header()
@@ -90,4 +94,5 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, stamps="--stamps" in sys.argv)
+    _def = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--define=")]
+    build(force="--force" in sys.argv, stamps="--stamps" in sys.argv, define=_def[0] if _def else "")

@@ -496,3 +496,28 @@ def test_graphed_step_refuses_a_changed_learning_rate(gpu_device):
     opt.param_groups[0]["lr"] = 5e-4                                   # what a scheduler does
     with pytest.raises(RuntimeError, match="changed after capture"):
         step(x, y)
+
+
+def test_rollout_fused_renormalisation_equals_decode_then_encode(gpu_device):
+    """f3: between rollout steps the reference decodes with the y-statistics and encodes with the x-statistics
+    (utils/autoregressive_step.py:296-303); with global statistics the product does it as one multiply-add"""
+    from dataloaders.ns_naive_markov import SimpleNormalizer
+    from models.ffno import FFNO1D
+    from utils.autoregressive_step import perform_rollout_1d, rollout_loss
+    torch.manual_seed(0)
+    m = FFNO1D(1, 1, width=16, n_layers=2, n_modes=8, factor=2, n_ff_layers=2, layer_norm=True).to(gpu_device).eval()
+    xn, yn = SimpleNormalizer(0.3, 1.7), SimpleNormalizer(-0.2, 0.9)
+    x0 = torch.randn(5, 64, device=gpu_device)
+    fused = perform_rollout_1d(m, x0, 4, device=gpu_device, x_normalizer=xn, y_normalizer=yn)
+    # the two-call leg, step by step
+    state, ref = x0, []
+    with torch.no_grad():
+        for _ in range(4):
+            nxt = m(state.unsqueeze(1)).squeeze(1)
+            ref.append(nxt.unsqueeze(1))
+            state = xn.encode(yn.decode(nxt, device=gpu_device))
+    ref = torch.cat(ref, dim=1)
+    assert float((fused - ref).norm() / ref.norm()) < 1e-5
+    traj = torch.randn(5, 5, 64, device=gpu_device)
+    per_step = sum(float((fused[:, t] - traj[:, t + 1]).norm(dim=-1).div(traj[:, t + 1].norm(dim=-1) + 1e-8).mean()) for t in range(4)) / 4
+    assert abs(rollout_loss(fused, traj) - per_step) < 1e-5
