@@ -218,7 +218,9 @@ def time_cfg5(device, B=8, iters=10):
         model = FNO2d(1, 1, modes1=12, modes2=12, width=32).to(device).eval()
         u = torch.randn(B, 1, 512, 512, generator=g).to(device)
         ms_model = _ev_time(lambda: model(u), iters)
-    return ms, 67.11e6 * B + 2.36e6, ms_model
+        u16 = torch.randn(16, 1, 512, 512, generator=g).to(device)
+        ms_model16 = _ev_time(lambda: model(u16), iters)
+    return ms, 67.11e6 * B + 2.36e6, ms_model, ms_model16
 
 
 def gpu_aten_baseline(B, device, hip_spec_ms, hip_spec_fb_ms, hip_ff_fwd_ms, hip_ff_fb_ms, hip_step_ms):
@@ -467,8 +469,9 @@ def main():
             f"bwd chain {ff['bwd_chain_ms']:.3f} ms, wgrad {ff['wgrad_ms']:.3f} ms")
         s_ms, s_gbs, s_bytes, s_bwd_ms, s_fb_ms = time_spectral(B, device)
         log(f"spectral fwd {s_ms:.3f} ms = {s_gbs:.0f} GB/s algorithmic; bwd {s_bwd_ms:.3f} ms")
-        c5_ms, c5_bytes, c5_model_ms = time_cfg5(device)
-        log(f"config 5: SpectralConv2d 512^2 forward {c5_ms:.3f} ms, FNO2d eval forward {c5_model_ms:.3f} ms (B=8)")
+        c5_ms, c5_bytes, c5_model_ms, c5_model16_ms = time_cfg5(device)
+        log(f"config 5: SpectralConv2d 512^2 forward {c5_ms:.3f} ms, FNO2d eval forward {c5_model_ms:.3f} ms (B=8), "
+            f"{c5_model16_ms:.3f} ms (B=16)")
         traffic = step_traffic = traffic_src = spec_traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -538,15 +541,22 @@ def main():
                     "mode mix, row DFT, k_cf_synthesis_h2), SURVEY 8(d): 67.11 MB*B + 2.36 MB", c5_bytes, c5_ms,
                     fno2d_512_eval_forward_ms_B8=round(c5_model_ms, 3),
                     fno2d_512_eval_samples_per_s=round(8 / c5_model_ms * 1e3, 1)),
+                # the whole evaluation forward of BASELINE config 5 against ITS ideal traffic: per sample 4 blocks x 67.11 MB
+                # (read x, write the activated block output) + lifting (write 33.55 MB) + projection (read 33.55 MB) + the
+                # 1-channel input and output (2 x 1.05 MB) = 337.6 MB
+                hbm("BASELINE config 5: FNO2d(1,1,12,12,32) evaluation forward at [16,1,512,512] (per block: k_cf_analysis_h2, two row "
+                    "DFTs + mode mix on the small spectra, then ONE pass for inverse DFT + bypass conv + GELU; fused projection MLP)",
+                    16 * 337.6e6, c5_model16_ms, samples_per_s=round(16 / c5_model16_ms * 1e3, 1)),
             ],
-            "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_dft_analysis_h2 (both axes, one launch) + mode mix "
-                                     "(2 GEMM) + k_spec_split_h2 (2) + k_dft_synthesis2_h2 (field written once)",
+            "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_mix_prep + k_dft_analysis_sq_h2 (both axes, the field read "
+                                     "from HBM once) + k_mix_h2 (mode mix of both axes, writes the synthesis operands) + "
+                                     "k_dft_synthesis3_h2 (field written once)",
                                      s_bytes, s_ms, traffic=spec_traffic,
                                      traffic_over_algorithmic=(round(spec_traffic / s_bytes, 3) if spec_traffic else None),
                                      backward_ms=round(s_bwd_ms, 4), backward_frac=round(2 * s_bytes / (s_bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                     note="x is read twice (once per axis; partial sums of the other axis "
-                                     "would be larger than the field), so 1.5x the algorithmic bytes is the floor of this "
-                                     "formulation: frac <= 0.52 at the 6.3 TB/s this box streams"),
+                                     note="HBM traffic of the four launches (PMC, profiles/): field 1x in + 1x out, spectra "
+                                     "written and read once as fp32 and once as operand fragments; the second read of the field "
+                                     "(the other axis) is served by the L2 of the XCD that read it first"),
         }
         if step_traffic:
             # whole training step against the HBM roof: PMC-measured bytes of one step / this run's step time

@@ -242,6 +242,23 @@ int rpde_conv1x1_fwd(const float* x, const float* w, const float* b, float* out,
  * out = act(spectral + W . x + b) written once, models/fno_blocks.py:25-45 of the reference) */
 int rpde_conv1x1_act_fwd(const float* x, const float* w, const float* b, float* out,
                          int B, int Cin, int Cout, int64_t S, int act_in, int accumulate, int act_out, void* stream);
+/* evaluation-mode FNOBlock2d in one entry point: out = act_out(SpectralConv2d(x; w1, w2) + Conv2d_1x1(x; wc, bc)),
+ * reference models/fno_blocks.py:63-83 with models/spectral_convolution.py:79-98.  The inverse DFT along the last
+ * axis, the bypass convolution, bias and activation run as ONE streaming pass over x: the spectral branch is never
+ * written.  x [B,Cin,M,N], w1/w2 complex [Cin,Cout,m1,m2] (as float pairs), wc [Cout,Cin], out [B,Cout,M,N].
+ * rpde_fnoblock2d_eval_ok: 1 when the shape is covered (Cout <= 32, N % 4 == 0, N divides 1024 or is a multiple of it). */
+size_t rpde_fnoblock2d_eval_ws_bytes(int B, int Cin, int Cout, int M, int N, int m1, int m2);
+int rpde_fnoblock2d_eval_ok(int Cin, int Cout, int M, int N);
+int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc, float* out,
+                             int B, int Cin, int Cout, int M, int N, int m1, int m2, int act_out,
+                             void* ws, size_t ws_bytes, void* stream);
+/* the projection MLP mlp2(gelu(mlp1(act_in(x)))) of models/fno_blocks.py:38-45,76-83 in one pass, EVALUATION only
+ * (the hidden tensor [B,Cmid,S] is never written; training keeps the two convolutions, whose backward needs it):
+ * x [B,Cin,S], w1 [Cmid,Cin], b1 [Cmid], w2 [Cout,Cmid], b2 [Cout], out [B,Cout,S].  rpde_conv_mlp_ok: 1 when the
+ * shape is covered (Cin 32 with Cmid <= 128, or Cin 64 with Cmid <= 64; Cout <= 4; S % 16 == 0). */
+int rpde_conv_mlp_ok(int Cin, int Cmid, int Cout, int64_t S);
+int rpde_conv_mlp_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+                      int B, int Cin, int Cmid, int Cout, int64_t S, int act_in, void* stream);
 int rpde_conv1x1_bwd(const float* x, const float* w, const float* grad_out,
                      float* grad_x, float* grad_w, float* grad_b,
                      int B, int Cin, int Cout, int64_t S, int act_in, int accumulate_gx,

@@ -67,6 +67,11 @@ bool cf_h2_eligible(int n, int R) {
   return n % 128 == 0 && R <= 32 && (n / 32) * NT * 2048 <= 65536;
 }
 
+// the synthesis kernel keeps n / 16 table fragments of 2 KB in its 64 KB table area: n <= 512.  (cf_h2_eligible alone let
+// n = 1024 with R <= 16 through -- its analysis table fits -- and the synthesis kernel then overran its LDS: NaNs.  Found
+// by tests/test_gpu_kernels.py::test_fused_evaluation_fnoblock2d_equals_the_two_step_path.)
+bool cf_h2_syn_eligible(int n, int R) { return cf_h2_eligible(n, R) && (n / 16) * 2048 <= 65536; }
+
 int cf_build_tables(rpde_plan* p, hipStream_t st) {
   const int R = 2 * p->kp, n = p->n, NT = (R + 15) / 16;
   const size_t ab = (size_t)(n / 32) * NT * 2048, sb = (size_t)(n / 16) * 2048;

@@ -14,19 +14,41 @@
 
 namespace rpde {
 
-template <int CO>      // outputs padded to CO in {4, 8, 16, 32}
+// the last stage of a channels-first spectral convolution folded into the same pass (evaluation-mode FNO block,
+// reference models/fno_blocks.py:63-83: activation(spectral_conv(x) + bypass_conv(x))): instead of reading the spectral
+// branch back from memory (accumulate) the kernel forms it -- out += sum_r Fs[n][r] t[b][o][m][r], the inverse real DFT
+// along the last axis of the row spectra t [B,Cout,M,R2] -- with the same fp32 multiply-adds that do the channel mix: R2
+// more "input channels" whose weights depend on the row.  The spectral branch never crosses HBM (2 x 33.5 MB per sample
+// and block at 512^2, width 32).
+struct ConvSyn {
+  const float* t;      // row spectra [B][Cout][M][R2]
+  const float* fs_t;   // synthesis table transposed [R2][N]
+  int M, N, R2;
+};
+
+template <int CO, bool SYN>      // outputs padded to CO in {4, 8, 16, 32}
 __global__ __launch_bounds__(256) void k_conv1x1_small(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int Cin,
-                                                       int Cout, long S, int act_in, int accumulate, int act_out) {
+                                                       int Cout, long S, int act_in, int accumulate, int act_out, ConvSyn Y) {
   extern __shared__ float wt[];                  // [Cin][CO]: for one input channel the CO weights are contiguous
   for (int e = threadIdx.x; e < Cin * CO; e += 256) {
     const int i = e / CO, o = e % CO;
     wt[e] = o < Cout ? w[o * Cin + i] : 0.f;
   }
+  const int b = blockIdx.y;
+  float* const ts = wt + Cin * CO;               // SYN: [rows of this block][R2][CO]
+  if (SYN) {
+    // a block covers 1024 consecutive points of a sample: 1024 / N whole rows (N <= 1024) or a piece of one row
+    const int rows = Y.N >= 1024 ? 1 : 1024 / Y.N;
+    const long m0 = ((long)blockIdx.x * 1024) / Y.N;
+    for (int e = threadIdx.x; e < rows * Y.R2 * CO; e += 256) {
+      const int o = e % CO, r = (e / CO) % Y.R2, row = e / (CO * Y.R2);
+      ts[e] = (o < Cout && m0 + row < Y.M) ? Y.t[(((long)b * Cout + o) * Y.M + m0 + row) * Y.R2 + r] : 0.f;
+    }
+  }
   __syncthreads();
   const long s4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (s4 >= S) return;
-  const int b = blockIdx.y;
   const float* __restrict__ xb = x + (long)b * Cin * S + s4;
   float* __restrict__ ob = out + (long)b * Cout * S + s4;
   float4 acc[CO];
@@ -54,6 +76,24 @@ __global__ __launch_bounds__(256) void k_conv1x1_small(const float* __restrict__
       }
     }
   }
+  if (SYN) {
+    const int n4 = (int)(s4 % Y.N);
+    const int row = Y.N >= 1024 ? 0 : (threadIdx.x * 4) / Y.N;
+    for (int r = 0; r < Y.R2; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(Y.fs_t + (long)r * Y.N + n4);
+      const float4* __restrict__ wr = reinterpret_cast<const float4*>(ts + (row * Y.R2 + r) * CO);
+#pragma unroll
+      for (int q = 0; q < CO / 4; ++q) {
+        const float4 ww = wr[q];
+        const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float4& a = acc[4 * q + k];
+          a.x = fmaf(wv[k], v.x, a.x); a.y = fmaf(wv[k], v.y, a.y); a.z = fmaf(wv[k], v.z, a.z); a.w = fmaf(wv[k], v.w, a.w);
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int o = 0; o < CO; ++o) {
     if (o < Cout) {
@@ -76,11 +116,37 @@ int conv1x1_small(const float* x, const float* w, const float* bias, float* out,
   const int CO = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : (Cout <= 16 ? 16 : 32));
   const dim3 grid((unsigned)((S / 4 + 255) / 256), B), block(256);
   const size_t lds = sizeof(float) * (size_t)Cin * CO;
+  ConvSyn Y{nullptr, nullptr, 0, 0, 0};
   switch (CO) {
-    case 4: hipLaunchKernelGGL(k_conv1x1_small<4>, grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out); break;
-    case 8: hipLaunchKernelGGL(k_conv1x1_small<8>, grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out); break;
-    case 16: hipLaunchKernelGGL(k_conv1x1_small<16>, grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out); break;
-    default: hipLaunchKernelGGL(k_conv1x1_small<32>, grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out); break;
+    case 4: hipLaunchKernelGGL((k_conv1x1_small<4, false>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out, Y); break;
+    case 8: hipLaunchKernelGGL((k_conv1x1_small<8, false>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out, Y); break;
+    case 16: hipLaunchKernelGGL((k_conv1x1_small<16, false>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out, Y); break;
+    default: hipLaunchKernelGGL((k_conv1x1_small<32, false>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, act_in, accumulate, act_out, Y); break;
+  }
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+// rows of N points: N a multiple of 4 that divides 1024 or is a multiple of it (a block's 1024 points are whole rows or
+// lie inside one)
+bool conv1x1_syn_ok(const float* x, const float* out, int Cin, int Cout, int M, int N) {
+  return conv1x1_small_ok(x, out, Cin, Cout, (long)M * N) && N % 4 == 0 && (1024 % N == 0 || N % 1024 == 0);
+}
+
+// out[b][o][m][n] = act_out(bias[o] + sum_i W[o][i] x[b][i][m][n] + sum_r fs_t[r][n] t[b][o][m][r])
+int conv1x1_syn(const float* x, const float* w, const float* bias, const float* t, const float* fs_t, float* out, int B, int Cin,
+                int Cout, int M, int N, int R2, int act_out, hipStream_t st) {
+  const long S = (long)M * N;
+  const int CO = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : (Cout <= 16 ? 16 : 32));
+  const dim3 grid((unsigned)((S / 4 + 255) / 256), B), block(256);
+  const int rows = N >= 1024 ? 1 : 1024 / N;
+  const size_t lds = sizeof(float) * ((size_t)Cin * CO + (size_t)rows * R2 * CO);
+  ConvSyn Y{t, fs_t, M, N, R2};
+  switch (CO) {
+    case 4: hipLaunchKernelGGL((k_conv1x1_small<4, true>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, 0, 0, act_out, Y); break;
+    case 8: hipLaunchKernelGGL((k_conv1x1_small<8, true>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, 0, 0, act_out, Y); break;
+    case 16: hipLaunchKernelGGL((k_conv1x1_small<16, true>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, 0, 0, act_out, Y); break;
+    default: hipLaunchKernelGGL((k_conv1x1_small<32, true>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, 0, 0, act_out, Y); break;
   }
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;

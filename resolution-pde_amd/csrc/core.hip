@@ -68,6 +68,13 @@ __global__ void k_real_synthesis(float* fs, int n, int modes, int kp, double si,
   fs[(long)y * 2 * kp + cim] = im;
 }
 
+__global__ void k_transpose_small(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int r = idx / cols, c = idx % cols;
+  out[(long)c * rows + r] = in[idx];
+}
+
 // complex forward DFT along an axis of length m restricted to R = top + bot row
 // slots (slot r < top -> bin r, else bin m - bot + (r - top)) as a real [2R, 2m] block
 // matrix; rows 2r+ri2, cols 2*mm+ri1.
@@ -143,6 +150,11 @@ static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, i
       if (n % 32 == 0 && n <= 256 && m2 <= 48) RPDE_TRY(h2_build_tables(p, st));
     }
     if (planar && p->ldn == n && cf_h2_eligible(n, 2 * p->kp)) RPDE_TRY(cf_build_tables(p, st));
+    if (planar) {
+      RPDE_HIP(hipMalloc(&p->fs_t, sizeof(float) * (size_t)n * 2 * p->kp));
+      const int tt = n * 2 * p->kp;
+      hipLaunchKernelGGL(k_transpose_small, dim3((tt + 255) / 256), dim3(256), 0, st, p->fs, p->fs_t, n, 2 * p->kp);
+    }
   } else {
     if (bot < 0) bot = modes;
     RPDE_CHECK_ARG(modes <= n && bot <= n && modes >= 0 && bot >= 0 && modes + bot >= 1, "plan: rows (%d,%d) vs M %d", modes, bot, n);
@@ -205,6 +217,7 @@ int rpde_plan_destroy(rpde_plan* p) {
   if (!p) return RPDE_OK;
   if (p->fa) (void)hipFree(p->fa);
   if (p->fs) (void)hipFree(p->fs);
+  if (p->fs_t) (void)hipFree(p->fs_t);
   for (int i = 0; i < 4; ++i) if (p->img[i]) (void)hipFree(p->img[i]);
   for (int i = 0; i < 2; ++i) {
     if (p->h2_ana[i]) (void)hipFree(p->h2_ana[i]);

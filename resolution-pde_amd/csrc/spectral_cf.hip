@@ -14,6 +14,7 @@
 // are ignored by the synthesis table exactly as torch does (quirk Q7).
 #include "rpde_internal.h"
 #include "plan.h"
+#include "conv_small.h"
 #include "pointwise.h"
 #include "cf_dft.h"
 #include "h2.h"
@@ -213,7 +214,7 @@ static int cf_analysis(const rpde_plan* pl, const float* x, float* spec, long ro
 // rows x 2kp -> rows x n  (C2R synthesis)
 static int cf_synthesis(const rpde_plan* pl, const float* spec, float* out, long rows, int n, hipStream_t st,
                         float alpha = 1.f) {
-  if (pl->cf_syn[0] && rows >= 16 && cf_h2_eligible(n, 2 * pl->kp)) return cf_synthesis_h2(pl, 0, spec, out, rows, alpha, st);
+  if (pl->cf_syn[0] && rows >= 16 && cf_h2_syn_eligible(n, 2 * pl->kp)) return cf_synthesis_h2(pl, 0, spec, out, rows, alpha, st);
   rpde_gemm_desc d = gemm_desc();
   d.alpha = alpha;
   d.A = spec; d.a_kmajor = 1; d.lda = 2L * pl->kp;
@@ -236,7 +237,7 @@ static int cf_synthesis_T(const rpde_plan* pl, const float* g, float* gspec, lon
 // adjoint of analysis: dspec[rows,2kp] . Fa -> gx[rows,n], through act'(x) when act_in
 static int cf_analysis_T(const rpde_plan* pl, const float* dspec, float* gx, long rows, int n, int act_in, const float* x,
                          hipStream_t st) {
-  if (!act_in && pl->cf_syn[1] && rows >= 16 && cf_h2_eligible(n, 2 * pl->kp)) return cf_synthesis_h2(pl, 1, dspec, gx, rows, 1.f, st);
+  if (!act_in && pl->cf_syn[1] && rows >= 16 && cf_h2_syn_eligible(n, 2 * pl->kp)) return cf_synthesis_h2(pl, 1, dspec, gx, rows, 1.f, st);
   rpde_gemm_desc d = gemm_desc();
   d.A = dspec; d.a_kmajor = 1; d.lda = 2L * pl->kp;
   d.B = pl->fa; d.b_kmajor = 0; d.ldb = pl->ldn;
@@ -358,6 +359,48 @@ int rpde_spectral2d_fwd(const float* x, const float* w1, const float* w2, float*
   RPDE_TRY(launch_mix(0, spec_in, nullptr, w1, w2, o2, nullptr, g, st));
   RPDE_TRY(cf_rowdft(pm->fs, 2L * R, false, 2 * M, 2 * R, o2, t1, B * Cout, kp, st));
   return cf_synthesis(pn, t1, out, (long)B * Cout * M, N, st);
+}
+
+// ---- evaluation-mode FNOBlock2d in the library: activation(SpectralConv2d(x) + bypass_conv(x)), reference
+// models/fno_blocks.py:63-83.  The spectral branch stops at the row spectra; the streaming kernel of conv_small.hip forms
+// the inverse DFT along the last axis, the 1x1 bypass convolution, bias and activation in one pass over x.
+size_t rpde_fnoblock2d_eval_ws_bytes(int B, int Cin, int Cout, int M, int N, int m1, int m2) {
+  return rpde_spectral2d_ws_bytes(B, Cin, Cout, M, N, m1, m2) + arena_bytes(rpde_spectral2d_spec_elems(B, Cin, M, N, m1, m2));
+}
+
+int rpde_fnoblock2d_eval_ok(int Cin, int Cout, int M, int N) {
+  // (pointer alignment is checked at the call; torch allocations are 256-byte aligned)
+  return conv1x1_syn_ok(nullptr, nullptr, Cin, Cout, M, N) ? 1 : 0;
+}
+
+int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc, float* out, int B,
+                             int Cin, int Cout, int M, int N, int m1, int m2, int act_out, void* ws, size_t ws_bytes,
+                             void* stream) {
+  RPDE_CHECK_ARG(x && w1 && w2 && wc && out && B > 0 && Cin > 0 && Cout > 0 && M > 0 && N > 0 && m1 > 0 && m2 > 0,
+                 "fnoblock2d_eval_fwd: bad arguments");
+  if (m2 > N / 2 + 1 || m1 > M) {
+    set_error("SpectralConv2d: modes (%d,%d) exceed the spectrum (%d,%d)", m1, m2, M, N / 2 + 1);
+    return RPDE_ERR_MODES;
+  }
+  RPDE_CHECK_ARG(conv1x1_syn_ok(x, out, Cin, Cout, M, N), "fnoblock2d_eval_fwd: shape not covered (%d -> %d on %d x %d)", Cin, Cout, M, N);
+  hipStream_t st = as_stream(stream);
+  const rpde_plan *pn, *pm;
+  RPDE_TRY(get_plan(&pn, N, m2, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));
+  RPDE_TRY(get_plan(&pm, M, m1, RPDE_NORM_BACKWARD, 0, PLAN_CPLX, st));
+  const int kp = pn->kp, R = 2 * m1;
+  Arena ar(ws, ws_bytes);
+  float* s1 = ar.take((size_t)B * Cin * M * 2 * kp);
+  float* t1 = ar.take((size_t)B * Cout * M * 2 * kp);
+  float* o2 = ar.take((size_t)B * Cout * 2 * R * kp);
+  float* s2 = ar.take((size_t)B * Cin * 2 * R * kp);
+  if (!ar.ok()) { set_error("fnoblock2d_eval_fwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  RPDE_TRY(cf_analysis(pn, x, s1, (long)B * Cin * M, N, 0, st));
+  RPDE_TRY(cf_rowdft(pm->fa, 2L * M, false, 2 * R, 2 * M, s1, s2, B * Cin, kp, st));
+  if (kp != m2) RPDE_HIP(hipMemsetAsync(o2, 0, sizeof(float) * (size_t)B * Cout * 2 * R * kp, st));
+  MixGeom g{B, Cin, Cout, R, m1, m2, kp};
+  RPDE_TRY(launch_mix(0, s2, nullptr, w1, w2, o2, nullptr, g, st));
+  RPDE_TRY(cf_rowdft(pm->fs, 2L * R, false, 2 * M, 2 * R, o2, t1, B * Cout, kp, st));
+  return conv1x1_syn(x, wc, bc, t1, pn->fs_t, out, B, Cin, Cout, M, N, 2 * kp, act_out, st);
 }
 
 int rpde_spectral2d_bwd(const float* grad_out, const float* spec_in, const float* w1, const float* w2, const float* x,

@@ -33,6 +33,12 @@ class _FNOBlock(nn.Module):
         """evaluation only: activation(spectral_conv(x) + bypass_conv(x)) with the activation applied by the
         kernel that writes the block's output (stored once, already activated, so that the next block's truncated
         DFT streams it without evaluating the activation again)"""
+        if isinstance(self.spectral_conv, SpectralConv2d):
+            # the spectral branch's last transform, the bypass convolution and the activation in one pass
+            out = ops.fnoblock2d_eval(x, self.spectral_conv.weights1, self.spectral_conv.weights2, self.bypass_conv.weight,
+                                      self.bypass_conv.bias, act_name(self.activation))
+            if out is not None:
+                return out
         spec = self.spectral_conv(x, "identity")
         return ops.conv1x1_act_eval(x, self.bypass_conv.weight, self.bypass_conv.bias, spec, act_name(self.activation))
 
@@ -61,6 +67,12 @@ class FNOBlock2d(_FNOBlock):
 
 class _MLP(nn.Module):
     def forward(self, x, act_in="identity"):
+        import torch
+        if not torch.is_grad_enabled():
+            # evaluation: one pass, the hidden tensor never reaches HBM (csrc/conv_mlp.hip)
+            out = ops.conv_mlp_eval(x, self.mlp1.weight, self.mlp1.bias, self.mlp2.weight, self.mlp2.bias, act_in)
+            if out is not None:
+                return out
         h = ops.conv1x1(x, self.mlp1.weight, self.mlp1.bias, act_in)
         return ops.conv1x1(h, self.mlp2.weight, self.mlp2.bias, "gelu")
 

@@ -424,6 +424,47 @@ def conv1x1_act_eval(x, w, b, acc, act_out: str):
     return out
 
 
+def fnoblock2d_eval(x, w1, w2, wc, bc, act_out: str):
+    """evaluation only (no autograd): act_out(SpectralConv2d(x; w1, w2) + conv1x1(x; wc, bc)) with the spectral branch's
+    last transform, the bypass convolution and the activation in one pass over x; None when the shape is not covered"""
+    lib = load()
+    if x.dim() != 4 or w1.shape[3] > x.shape[-1] // 2 + 1 or w1.shape[2] > x.shape[-2]:
+        return None
+    B, Ci, M, N = x.shape
+    Co, m1, m2 = w1.shape[1], w1.shape[2], w1.shape[3]
+    if not lib.rpde_fnoblock2d_eval_ok(Ci, Co, M, N):
+        return None
+    x = _f32c(x)
+    wcf = _f32c(wc.detach()).reshape(Co, Ci)
+    bcf = _f32c(bc.detach()) if bc is not None else None
+    out = torch.empty(B, Co, M, N, dtype=torch.float32, device=x.device)
+    nws = lib.rpde_fnoblock2d_eval_ws_bytes(B, Ci, Co, M, N, m1, m2)
+    ws = workspace(nws, x.device)
+    check(lib.rpde_fnoblock2d_eval_fwd(ptr(x), ptr(_as_float_storage(w1.detach())), ptr(_as_float_storage(w2.detach())), ptr(wcf),
+                                       ptr(bcf), ptr(out), B, Ci, Co, M, N, m1, m2, ACT[act_out], ws.data_ptr(), nws,
+                                       stream_ptr()), "fnoblock2d_eval_fwd")
+    return out
+
+
+def conv_mlp_eval(x, w1, b1, w2, b2, act_in: str = "identity"):
+    """evaluation only (no autograd): mlp2(gelu(mlp1(act_in(x)))) of the FNO projection in one pass, or None when the
+    shape is not covered (the caller then runs the two convolutions)"""
+    lib = load()
+    B, Ci = x.shape[0], x.shape[1]
+    S = x[0, 0].numel()
+    Cm, Co = w1.shape[0], w2.shape[0]
+    if not lib.rpde_conv_mlp_ok(Ci, Cm, Co, S):
+        return None
+    x = _f32c(x)
+    w1f, w2f = _f32c(w1.detach()).reshape(Cm, Ci), _f32c(w2.detach()).reshape(Co, Cm)
+    b1f = _f32c(b1.detach()) if b1 is not None else None
+    b2f = _f32c(b2.detach()) if b2 is not None else None
+    out = torch.empty(B, Co, *x.shape[2:], dtype=torch.float32, device=x.device)
+    check(lib.rpde_conv_mlp_fwd(ptr(x), ptr(w1f), ptr(b1f), ptr(w2f), ptr(b2f), ptr(out), B, Ci, Cm, Co, S, ACT[act_in],
+                                stream_ptr()), "conv_mlp_fwd")
+    return out
+
+
 class _Act(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act: int):

@@ -341,3 +341,66 @@ def test_native_fp32_mfma_path_stays_green(gpu_device):
                         os.path.join(here, "test_gpu_golden.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 128, 1, 64 * 48), (1, 32, 100, 3, 256), (2, 64, 64, 2, 512), (1, 32, 16, 1, 16)])
+@pytest.mark.parametrize("act_in", ["identity", "gelu"])
+def test_fused_projection_mlp_matches_float64(gpu_device, shape, act_in):
+    """csrc/conv_mlp.hip: mlp2(gelu(mlp1(act_in(x)))) in one pass (evaluation) against float64 and the two-convolution path"""
+    import os
+    import torch.nn.functional as F
+    from rpde import ops
+    B, Ci, Cm, Co, S = shape
+    torch.manual_seed(Ci + Cm + S)
+    x = torch.randn(B, Ci, S, device=gpu_device) * 3.0
+    x[:, :, ::7] *= 1e-3                                   # tiles of very different magnitude
+    w1 = torch.randn(Cm, Ci, 1, device=gpu_device) * 0.3
+    b1 = torch.randn(Cm, device=gpu_device) * 0.2
+    w2 = torch.randn(Co, Cm, 1, device=gpu_device) * 0.2
+    b2 = torch.randn(Co, device=gpu_device)
+    with torch.no_grad():
+        got = ops.conv_mlp_eval(x, w1, b1, w2, b2, act_in)
+        assert got is not None
+        xa = F.gelu(x.double()) if act_in == "gelu" else x.double()
+        ref = F.conv1d(F.gelu(F.conv1d(xa, w1.double(), b1.double())), w2.double(), b2.double())
+        two = ops.conv1x1(ops.conv1x1(x, w1, b1, act_in), w2, b2, "gelu")
+    e = float((got.double() - ref).norm() / ref.norm())
+    e2 = float((two.double() - ref).norm() / ref.norm())
+    assert e < 2e-6, (e, e2)
+    old = os.environ.get("RPDE_CONV_MLP")
+    os.environ["RPDE_CONV_MLP"] = "0"
+    try:
+        assert ops.conv_mlp_eval(x, w1, b1, w2, b2, act_in) is None
+    finally:
+        if old is None:
+            os.environ.pop("RPDE_CONV_MLP")
+        else:
+            os.environ["RPDE_CONV_MLP"] = old
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64, 12, 12), (1, 8, 6, 48, 256, 5, 9), (2, 4, 4, 16, 1024, 3, 4)])
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_fused_evaluation_fnoblock2d_equals_the_two_step_path(gpu_device, shape, act):
+    """rpde_fnoblock2d_eval_fwd (conv_small.hip SYN): act(SpectralConv2d(x) + bypass(x)) in one pass against the
+    spectral op followed by the accumulating convolution, and against float64"""
+    from rpde import ops
+    B, Ci, Co, M, N, m1, m2 = shape
+    torch.manual_seed(M + N + Ci)
+    x = torch.randn(B, Ci, M, N, device=gpu_device)
+    w1 = (torch.rand(Ci, Co, m1, m2, dtype=torch.cfloat) / (Ci * Co)).to(gpu_device)
+    w2 = (torch.rand(Ci, Co, m1, m2, dtype=torch.cfloat) / (Ci * Co)).to(gpu_device)
+    wc = torch.randn(Co, Ci, 1, 1, device=gpu_device) * 0.2
+    bc = torch.randn(Co, device=gpu_device) * 0.1
+    with torch.no_grad():
+        got = ops.fnoblock2d_eval(x, w1, w2, wc, bc, act)
+        assert got is not None
+        spec = ops.spectral2d(x, w1, w2)
+        two = ops.conv1x1_act_eval(x, wc, bc, spec.clone(), act)
+        xf = torch.fft.rfft2(x.double().cpu())
+        o = torch.zeros(B, Co, M, N // 2 + 1, dtype=torch.complex128)
+        o[:, :, :m1, :m2] = torch.einsum("bixy,ioxy->boxy", xf[:, :, :m1, :m2], w1.cpu().to(torch.complex128))
+        o[:, :, -m1:, :m2] = torch.einsum("bixy,ioxy->boxy", xf[:, :, -m1:, :m2], w2.cpu().to(torch.complex128))
+        pre = torch.fft.irfft2(o, s=(M, N)) + torch.nn.functional.conv2d(x.double().cpu(), wc.double().cpu(), bc.double().cpu())
+        ref = torch.nn.functional.gelu(pre) if act == "gelu" else torch.relu(pre)
+    assert float((got.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+    assert float((got - two).norm() / two.norm()) < 2e-6
