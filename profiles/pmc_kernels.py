@@ -17,7 +17,7 @@ def main(dirs):
                 name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void rpde::", "").replace("rpde::", "")[:60]
                 acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for name, cs in sorted(acc.items()):
-        if not any(k in name for k in ("k_dft", "k_spec", "gemm", "k_ff", "k_mix")):
+        if not any(k in name for k in ("k_dft", "k_spec", "gemm", "k_ff", "k_mix", "k_wgrad", "k_conv", "k_cf")):
             continue
         print(name)
         for c, v in sorted(cs.items()):

@@ -26,6 +26,16 @@ struct ConvSyn {
   int M, N, R2;
 };
 
+// acc (four points) += w * v as two packed fp32 multiply-adds (v_pk_fma_f32: two per lane and instruction -- this kernel
+// has no matrix work that packed fp32 would get in the way of, and with the synthesis folded in it is bound by these)
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+struct Acc4 { f32x2v lo, hi; };
+__device__ __forceinline__ void fma4(Acc4& a, float w, const float4& v) {
+  const f32x2v ww = {w, w};
+  a.lo = __builtin_elementwise_fma(ww, (f32x2v){v.x, v.y}, a.lo);
+  a.hi = __builtin_elementwise_fma(ww, (f32x2v){v.z, v.w}, a.hi);
+}
+
 template <int CO, bool SYN>      // outputs padded to CO in {4, 8, 16, 32}
 __global__ __launch_bounds__(256) void k_conv1x1_small(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int Cin,
@@ -51,16 +61,17 @@ __global__ __launch_bounds__(256) void k_conv1x1_small(const float* __restrict__
   if (s4 >= S) return;
   const float* __restrict__ xb = x + (long)b * Cin * S + s4;
   float* __restrict__ ob = out + (long)b * Cout * S + s4;
-  float4 acc[CO];
+  Acc4 acc[CO];
 #pragma unroll
   for (int o = 0; o < CO; ++o) {
     const float bo = (bias && o < Cout) ? bias[o] : 0.f;
-    acc[o] = make_float4(bo, bo, bo, bo);
+    acc[o].lo = (f32x2v){bo, bo}; acc[o].hi = (f32x2v){bo, bo};
     if (accumulate && o < Cout) {
       const float4 p = *reinterpret_cast<const float4*>(ob + (long)o * S);
-      acc[o].x += p.x; acc[o].y += p.y; acc[o].z += p.z; acc[o].w += p.w;
+      acc[o].lo += (f32x2v){p.x, p.y}; acc[o].hi += (f32x2v){p.z, p.w};
     }
   }
+  // (unrolling this loop for more loads in flight per thread was measured slower: 256 VGPRs, one wave per SIMD fewer)
   for (int i = 0; i < Cin; ++i) {
     float4 v = *reinterpret_cast<const float4*>(xb + (long)i * S);
     if (act_in) { v.x = act_f(act_in, v.x); v.y = act_f(act_in, v.y); v.z = act_f(act_in, v.z); v.w = act_f(act_in, v.w); }
@@ -68,12 +79,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_small(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < CO / 4; ++q) {
       const float4 ww = wr[q];
-      const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float4& a = acc[4 * q + k];
-        a.x = fmaf(wv[k], v.x, a.x); a.y = fmaf(wv[k], v.y, a.y); a.z = fmaf(wv[k], v.z, a.z); a.w = fmaf(wv[k], v.w, a.w);
-      }
+      fma4(acc[4 * q], ww.x, v); fma4(acc[4 * q + 1], ww.y, v); fma4(acc[4 * q + 2], ww.z, v); fma4(acc[4 * q + 3], ww.w, v);
     }
   }
   if (SYN) {
@@ -85,19 +91,14 @@ __global__ __launch_bounds__(256) void k_conv1x1_small(const float* __restrict__
 #pragma unroll
       for (int q = 0; q < CO / 4; ++q) {
         const float4 ww = wr[q];
-        const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float4& a = acc[4 * q + k];
-          a.x = fmaf(wv[k], v.x, a.x); a.y = fmaf(wv[k], v.y, a.y); a.z = fmaf(wv[k], v.z, a.z); a.w = fmaf(wv[k], v.w, a.w);
-        }
+        fma4(acc[4 * q], ww.x, v); fma4(acc[4 * q + 1], ww.y, v); fma4(acc[4 * q + 2], ww.z, v); fma4(acc[4 * q + 3], ww.w, v);
       }
     }
   }
 #pragma unroll
   for (int o = 0; o < CO; ++o) {
     if (o < Cout) {
-      float4 a = acc[o];
+      float4 a = make_float4(acc[o].lo.x, acc[o].lo.y, acc[o].hi.x, acc[o].hi.y);
       if (act_out) { a.x = act_f(act_out, a.x); a.y = act_f(act_out, a.y); a.z = act_f(act_out, a.z); a.w = act_f(act_out, a.w); }
       *reinterpret_cast<float4*>(ob + (long)o * S) = a;
     }
