@@ -179,6 +179,16 @@ static bool fused_mix_on() {
   return !(e && e[0] == '0');
 }
 
+// slabs of lines for the h2 weight gradient of the mix: enough workgroups to fill the chip (keff x S x 2), at least four
+// 32-line tiles each
+static int mixw_slabs(const Axis& ay, const Axis& ax) {
+  const long tiles = (ay.rows < ax.rows ? ay.rows : ax.rows) / 32;
+  long S = tiles / 4;
+  if (S > 12) S = 12;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
 static size_t fused2d_ws(const Axis& ay, const Axis& ax, int C, bool backward) {
   const size_t spy = arena_bytes(spec_floats(ay, C)), spx = arena_bytes(spec_floats(ax, C));
   const size_t wblk = arena_bytes((size_t)ay.keff * 4 * C * C);
@@ -190,7 +200,7 @@ static size_t fused2d_ws(const Axis& ay, const Axis& ax, int C, bool backward) {
   if (backward) {
     const int Sy = split_for(ay.rows, wgrad_tiles(C) * ay.keff), Sx = split_for(ax.rows, wgrad_tiles(C) * ax.keff);
     const size_t sl = arena_bytes((size_t)(Sy > Sx ? Sy : Sx) * ay.keff * 4 * C * C);
-    n += spy + spx + sl;
+    n += spy + spx + sl + arena_bytes(mix_wgrad_slab_floats(ay.kp, mixw_slabs(ay, ax)));
   }
   return n;
 }
@@ -206,8 +216,9 @@ static int fused2d_fwd(const Axis& ay, const Axis& ax, const float* x, const flo
   float* invx = ar.take(ax.rows);
   void* wimg = ar.take(mix_wimg_bytes(ay.kp) / 4);
   float* wc = ar.take(4 * (size_t)ay.kp);
-  float* amy = ar.take(ay.rows);
-  float* amx = ar.take(ax.rows);
+  // max |spectrum| per line: kept behind the saved spectra (rpde_fspectral2d_spec_elems), the backward needs them too
+  float* amy = spec_y + spec_floats(ay, C);
+  float* amx = spec_x + spec_floats(ax, C);
   if (!ar.ok()) { set_error("fspectral2d: workspace too small"); return RPDE_ERR_WORKSPACE; }
   if (mode == RPDE_MODE_FULL && fused_mix_on()) {
     // prep (weights -> fragments) | analysis (+ max per line) | mix (spectra -> operand blocks) | synthesis
@@ -254,13 +265,21 @@ static int fused2d_bwd(const Axis& ay, const Axis& ax, const float* g, const flo
   float* wc = ar.take(4 * (size_t)ay.kp);
   float* amy = ar.take(ay.rows);
   float* amx = ar.take(ax.rows);
+  const int Sw = mixw_slabs(ay, ax);
+  float* wslabs = ar.take(mix_wgrad_slab_floats(ay.kp, Sw));
   if (!ar.ok()) { set_error("fspectral2d: workspace too small"); return RPDE_ERR_WORKSPACE; }
-  const bool hmix = mode == RPDE_MODE_FULL && gx && fused_mix_on();
+  const bool h2mix = mode == RPDE_MODE_FULL && fused_mix_on();
+  const bool hmix = h2mix && gx, hwg = h2mix && (gwy || gwx);
   if (hmix) RPDE_TRY(mix_prep(w_y, w_x, K, ay.keff, ay.kp, 1, wimg, wc, st));
-  RPDE_TRY(fused2d_analysis(g, gsy, gsx, hmix ? amy : nullptr, hmix ? amx : nullptr, ay.plan, ax.plan, 1, B, M, N, st));
+  RPDE_TRY(fused2d_analysis(g, gsy, gsx, h2mix ? amy : nullptr, h2mix ? amx : nullptr, ay.plan, ax.plan, 1, B, M, N, st));
   if (hmix) {
     // d-spectra = g-spectra . W^H, straight into the operand blocks of the adjoint synthesis
     RPDE_TRY(mix_h2(gsy, gsx, amy, amx, imgy, imgx, invy, invx, ay.rows, ax.rows, ay.kp, wimg, wc, st));
+  }
+  if (hwg) {
+    // weight gradients of both axes from the saved spectra (their line maxima sit behind them) and the g-spectra
+    RPDE_TRY(mix_wgrad_h2(spec_y, spec_x, gsy, gsx, spec_y + spec_floats(ay, C), spec_x + spec_floats(ax, C), amy, amx, gwy, gwx,
+                          ay.rows, ax.rows, K, ay.keff, ay.kp, wslabs, Sw, st));
   }
   const Axis* axes[2] = {&ay, &ax};
   const float* ws_[2] = {w_y, w_x};
@@ -274,7 +293,7 @@ static int fused2d_bwd(const Axis& ay, const Axis& ax, const float* g, const flo
     const Axis& A = *axes[a];
     const float* dspec = gspecs[a];
     if (mode == RPDE_MODE_FULL) {
-      if (gws[a]) {
+      if (gws[a] && !hwg) {
         RPDE_TRY(mode_mix_wgrad(A, specs[a], gspecs[a], slabs, C, Ss[a], st));
         RPDE_TRY(unpack_mix_grad(slabs, gws[a], C, C, K, A.keff, Ss[a], (long)A.keff * 4 * C * C, st));
       }
@@ -344,9 +363,11 @@ size_t rpde_fspectral2d_ws_bytes(int B, int M, int N, int C, int K) {
   return n;
 }
 size_t rpde_fspectral2d_spec_elems(int B, int M, int N, int C, int K, int axis) {
-  Axis a;
-  if (axis == 0) axis_dims(a, N, K, B * M); else axis_dims(a, M, K, B * N);
-  return spec_floats(a, C);
+  Axis a, o;
+  if (axis == 0) { axis_dims(a, N, K, B * M); axis_dims(o, M, K, B * N); } else { axis_dims(a, M, K, B * N); axis_dims(o, N, K, B * M); }
+  // fused path: the line maxima of the spectrum ride behind it (the backward's weight-gradient kernel scales by them)
+  const bool fused = axis == 0 ? fused2d_ok(M, N, C, a.keff, o.keff) : fused2d_ok(M, N, C, o.keff, a.keff);
+  return spec_floats(a, C) + (fused ? (size_t)a.rows : 0);
 }
 
 int rpde_fspectral2d_fwd(const float* x, const float* w_y, const float* w_x, float* out, float* spec_y, float* spec_x, int B,

@@ -267,6 +267,159 @@ __global__ __launch_bounds__(256, 2) void k_mix_h2(const MixP P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient of the mode mix:  gWr[i][o] = sum_lines (re_i gre_o + im_i gim_o),  gWi[i][o] = sum_lines (re_i gim_o
+// - im_i gre_o)  per axis and mode, from the saved spectra and the gradient spectra (both [line][k][re|im][64] fp32).
+// The reduction runs over the LINES, so both MFMA operands need the line index as k: a tile of 32 lines x (re | im) x 64
+// channels of each tensor is staged in LDS as f16 pieces in memory order and read back with transposing reads
+// (ds_read_b64_tr_b16) -- the same register image serves as A operand (rows = channels i) and as B operand (columns =
+// channels o).  Wave w owns the output rows i = 16w .. 16w + 15 of both gWr and gWi (8 accumulator tiles); one
+// workgroup per (axis, mode, slab of lines); slabs are folded in fixed order by k_mix_wgrad_fold.  One power-of-two
+// scale per tensor and axis, from the line maxima the analysis kernels leave (a product's error scales with the OTHER
+// operand's magnitude, so modes far below the maximum keep their relative accuracy).
+// Replaces the 128 x 128 real-block GEMM + unpack per axis of round 2 (2 x (52 + 26) us at B = 32).
+// ------------------------------------------------------------------------------------------------------------
+struct MixWgP {
+  const float* spec[2]; const float* gspec[2];   // [lines][R][64]
+  const float* amax_s[2]; const float* amax_g[2];
+  float* slabs;                                   // [S][axis][kp][64][64][2]
+  long lines[2];
+  int kp, keff, R, S;
+};
+
+__device__ __forceinline__ int mixw_stage_off(int k, int c8) {      // = stage_off of fused_spectral.hip
+  return k * 128 + ((c8 ^ ((((k >> 1) & 1) << 2) | (((k >> 3) & 1) << 3))) << 3);
+}
+
+__global__ __launch_bounds__(256, 2) void k_mix_wgrad_h2(const MixWgP P) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 8192];      // pieces spec re, spec im, g re, g im: [hi 4 KB | lo 4 KB]
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, li = l & 15;
+  const int k = blockIdx.x, s = blockIdx.y, a = blockIdx.z;
+  const long lines = P.lines[a];
+  const long tiles = lines / 32, tps = (tiles + P.S - 1) / P.S;
+  const long t0 = s * tps, t1 = min(t0 + tps, tiles);
+  float* const slab = P.slabs + (((long)s * 2 + a) * P.kp + k) * (64 * 64 * 2);
+  // ---- scales: max over the axis' line maxima ----
+  float ms = 0.f, mg = 0.f;
+  for (long i = tid; i < lines; i += 256) { ms = fmaxf(ms, P.amax_s[a][i]); mg = fmaxf(mg, P.amax_g[a][i]); }
+  ms = wave_max(ms); mg = wave_max(mg);
+  if (l == 0) { red[0][w] = ms; red[1][w] = mg; }
+  __syncthreads();
+  ms = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  mg = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  float sc_s, iv_s, sc_g, iv_g;
+  h2_scale(ms, 0, sc_s, iv_s);
+  h2_scale(mg, 0, sc_g, iv_g);
+
+  // staging: thread -> line tid >> 3 of the tile, 16 consecutive floats (tid & 7) of the line's 128 (re 64 | im 64)
+  const int sl = tid >> 3, ch = tid & 7, part = ch >> 2, c80 = 4 * (ch & 3);
+  const long lstride = (long)P.R * 64;
+  float4 rs[4], rg[4];
+  auto issue = [&](long t) {
+    const long off = (t * 32 + sl) * lstride + k * 128 + ch * 16;
+    const float4* ps = reinterpret_cast<const float4*>(P.spec[a] + off);
+    const float4* pg = reinterpret_cast<const float4*>(P.gspec[a] + off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rs[i] = ps[i]; rg[i] = pg[i]; }
+  };
+  auto put = [&](const float4 (&r)[4], int piece, float sc) {
+    char* base = smem + piece * 8192;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 hi, lo;
+      h2_split4(r[i].x * sc, r[i].y * sc, r[i].z * sc, r[i].w * sc, hi, lo);
+      const int off = mixw_stage_off(sl, c80 + i);
+      *reinterpret_cast<uint2*>(base + off) = hi;
+      *reinterpret_cast<uint2*>(base + 4096 + off) = lo;
+    }
+  };
+  // transposing-read address of this lane inside a piece (k_dft_analysis_h2's): rows 8g + q / 8g + 4 + q, chunk pp
+  typedef s16x4v __attribute__((address_space(3))) * lds_tr;
+  const int q = li >> 2, pp = li & 3;
+  const int tsw = ((q >> 1) & 1) | ((g & 1) << 1);
+  const int trow = (8 * g + q) * 128 + pp * 8;
+  auto frag = [&](int piece, int hl, int ctile) {           // 8 lines (k = 8g + j) of channel 16 ctile + li
+    const char* t = smem + piece * 8192 + hl * 4096 + trow + ((ctile ^ tsw) << 5);
+    union { struct { s16x4v a, b; } h; f16x8 v; } u;
+    u.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t));
+    u.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 512));
+    return u.v;
+  };
+  f32x4v cr[4], ci[4];
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot) { cr[ot] = (f32x4v){0.f, 0.f, 0.f, 0.f}; ci[ot] = (f32x4v){0.f, 0.f, 0.f, 0.f}; }
+  if (t0 < t1) issue(t0);
+  for (long t = t0; t < t1; ++t) {
+    put(rs, part, sc_s);              // pieces 0 / 1: spectra re / im
+    put(rg, 2 + part, sc_g);          // pieces 2 / 3: gradient spectra re / im
+    if (t + 1 < t1) issue(t + 1);
+    lds_barrier_mix();
+    // A operands: this wave's 16 channels i of the saved spectra
+    const f16x8 reh = frag(0, 0, w), rel = frag(0, 1, w), imh = frag(1, 0, w), iml = frag(1, 1, w);
+    f16x8 nih, nil;
+    {
+      typedef unsigned u4v __attribute__((ext_vector_type(4)));
+      union { f16x8 v; u4v u; } x, y;
+      x.v = imh; y.v = iml;
+      x.u ^= 0x80008000u; y.u ^= 0x80008000u;
+      nih = x.v; nil = y.v;
+    }
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+      const f16x8 grh = frag(2, 0, ot), grl = frag(2, 1, ot), gih = frag(3, 0, ot), gil = frag(3, 1, ot);
+      cr[ot] = h2_mfma32(reh, rel, grh, grl, cr[ot]);
+      cr[ot] = h2_mfma32(imh, iml, gih, gil, cr[ot]);
+      ci[ot] = h2_mfma32(reh, rel, gih, gil, ci[ot]);
+      ci[ot] = h2_mfma32(nih, nil, grh, grl, ci[ot]);
+    }
+    lds_barrier_mix();
+  }
+  // rows i = 16 w + 4 g + jj, column o = 16 ot + li: (gWr, gWi) pairs
+  const float inv = iv_s * iv_g;
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int i = 16 * w + 4 * g + jj, o = 16 * ot + li;
+      *reinterpret_cast<float2*>(slab + (i * 64 + o) * 2) = make_float2(cr[ot][jj] * inv, ci[ot][jj] * inv);
+    }
+}
+
+// gw[i][o][k][2] = sum_s slabs[s][axis][k][i][o][2]; zero for k >= keff
+__global__ __launch_bounds__(256) void k_mix_wgrad_fold(const float* __restrict__ slabs, float* __restrict__ gw_y,
+                                                        float* __restrict__ gw_x, int K, int keff, int kp, int S) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;        // (i * 64 + o) * K + k
+  const int a = blockIdx.y;
+  if (idx >= 4096L * K) return;
+  const int k = (int)(idx % K);
+  const long io = idx / K;
+  float2 acc = make_float2(0.f, 0.f);
+  if (k < keff)
+    for (int s = 0; s < S; ++s) {
+      const float2 v = *reinterpret_cast<const float2*>(slabs + ((((long)s * 2 + a) * kp + k) * 4096 + io) * 2);
+      acc.x += v.x; acc.y += v.y;
+    }
+  float* gw = a ? gw_x : gw_y;
+  if (gw) *reinterpret_cast<float2*>(gw + idx * 2) = acc;
+}
+
+size_t mix_wgrad_slab_floats(int kp, int S) { return (size_t)S * 2 * kp * 64 * 64 * 2; }
+
+int mix_wgrad_h2(const float* spec_y, const float* spec_x, const float* gspec_y, const float* gspec_x, const float* amax_sy,
+                 const float* amax_sx, const float* amax_gy, const float* amax_gx, float* gw_y, float* gw_x, long lines_y,
+                 long lines_x, int K, int keff, int kp, float* slabs, int S, hipStream_t st) {
+  MixWgP P;
+  P.spec[0] = spec_y; P.spec[1] = spec_x; P.gspec[0] = gspec_y; P.gspec[1] = gspec_x;
+  P.amax_s[0] = amax_sy; P.amax_s[1] = amax_sx; P.amax_g[0] = amax_gy; P.amax_g[1] = amax_gx;
+  P.slabs = slabs; P.lines[0] = lines_y; P.lines[1] = lines_x; P.kp = kp; P.keff = keff; P.R = 2 * kp; P.S = S;
+  hipLaunchKernelGGL(k_mix_wgrad_h2, dim3(keff, S, 2), dim3(256), 0, st, P);
+  RPDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_mix_wgrad_fold, dim3((unsigned)((4096L * K + 255) / 256), 2), dim3(256), 0, st, slabs, gw_y, gw_x, K, keff, kp, S);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
 #define RPDE_MIX_DISPATCH(R, ...)                                                           \
   do {                                                                                          \
     switch ((R) / 8) {                                                                          \

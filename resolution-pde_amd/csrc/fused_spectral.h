@@ -31,6 +31,12 @@ constexpr int MIX_W_BYTES_PER_MODE = 4 * 2 * 2 * 2 * 1024;      // [cb 4][Wr|Wi]
 size_t mix_wimg_bytes(int kp);
 // weights of both axes -> fragment image + wc[2][kp][2] = {1 / scale, norm}; conj_t: W^H (the adjoint's operand)
 int mix_prep(const float* w_y, const float* w_x, int K, int keff, int kp, int conj_t, void* wimg, float* wc, hipStream_t st);
+// weight gradients of the mix, both axes: two launches (slabs of lines, then a fixed-order fold); amax_*: line maxima of the
+// saved spectra / of the gradient spectra; slabs: mix_wgrad_slab_floats(kp, S) floats of workspace
+size_t mix_wgrad_slab_floats(int kp, int S);
+int mix_wgrad_h2(const float* spec_y, const float* spec_x, const float* gspec_y, const float* gspec_x, const float* amax_sy,
+                 const float* amax_sx, const float* amax_gy, const float* amax_gx, float* gw_y, float* gw_x, long lines_y,
+                 long lines_x, int K, int keff, int kp, float* slabs, int S, hipStream_t st);
 int mix_h2(const float* spec_y, const float* spec_x, const float* amax_y, const float* amax_x, void* img_y, void* img_x,
            float* inv_y, float* inv_x, long lines_y, long lines_x, int kp, const void* wimg, const float* wc, hipStream_t st);
 
