@@ -56,10 +56,26 @@ __global__ __launch_bounds__(1024) void k_ff3_prep(const float* __restrict__ w1,
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   // [0..2] max |W1|, |W2|, |W3|; [3] max row L1 of W1; [4] of W2; [5] max(|b1|), [6] max(|b2|) folded into 3,4 slots below
   float m1 = 0.f, m2 = 0.f, m3 = 0.f, r1 = 0.f, r2 = 0.f, bm = 0.f;
-#pragma unroll 8
-  for (int i = tid; i < 256 * 64; i += 1024) { m1 = fmaxf(m1, fabsf(w1[i])); m3 = fmaxf(m3, fabsf(w3[i])); }
-#pragma unroll 16
-  for (int i = tid; i < 256 * 256; i += 1024) m2 = fmaxf(m2, fabsf(w2[i]));
+  // (16-byte loads, everything of a thread in flight at once: this launch sits in front of every forward, and its
+  //  32 us were load latency, not work)
+  {
+    const float4* w14 = reinterpret_cast<const float4*>(w1);
+    const float4* w34 = reinterpret_cast<const float4*>(w3);
+    const float4* w24 = reinterpret_cast<const float4*>(w2);
+    float4 a[4], c[4], b[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = w14[tid + 1024 * i]; c[i] = w34[tid + 1024 * i]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = w24[tid + 1024 * i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(a[i].x), fabsf(a[i].y)), fmaxf(fabsf(a[i].z), fabsf(a[i].w))));
+      m3 = fmaxf(m3, fmaxf(fmaxf(fabsf(c[i].x), fabsf(c[i].y)), fmaxf(fabsf(c[i].z), fabsf(c[i].w))));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m2 = fmaxf(m2, fmaxf(fmaxf(fabsf(b[i].x), fabsf(b[i].y)), fmaxf(fabsf(b[i].z), fabsf(b[i].w))));
+  }
+#pragma unroll 4
   for (int row = wv; row < 256; row += 16) {          // row L1 norms, one wave per row (coalesced)
     float a = fabsf(w1[row * 64 + l]);
     float b = (fabsf(w2[row * 256 + l]) + fabsf(w2[row * 256 + 64 + l])) + (fabsf(w2[row * 256 + 128 + l]) + fabsf(w2[row * 256 + 192 + l]));
@@ -471,15 +487,39 @@ __global__ __launch_bounds__(1024) void k_ff3_prep_bwd(const float* __restrict__
   __shared__ float fin[5];
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   float m1 = 0.f, m2 = 0.f, m3 = 0.f, r3 = 0.f, r2 = 0.f;
-#pragma unroll 8
-  for (int i = tid; i < 256 * 64; i += 1024) { m1 = fmaxf(m1, fabsf(w1[i])); m3 = fmaxf(m3, fabsf(w3[i])); }
-#pragma unroll 16
-  for (int i = tid; i < 256 * 256; i += 1024) m2 = fmaxf(m2, fabsf(w2[i]));
-  if (tid < 256) {               // column L1 norms: what bounds a row of the transposed products
+  {
+    const float4* w14 = reinterpret_cast<const float4*>(w1);
+    const float4* w34 = reinterpret_cast<const float4*>(w3);
+    const float4* w24 = reinterpret_cast<const float4*>(w2);
+    float4 a[4], c[4], b[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = w14[tid + 1024 * i]; c[i] = w34[tid + 1024 * i]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = w24[tid + 1024 * i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(a[i].x), fabsf(a[i].y)), fmaxf(fabsf(a[i].z), fabsf(a[i].w))));
+      m3 = fmaxf(m3, fmaxf(fmaxf(fabsf(c[i].x), fabsf(c[i].y)), fmaxf(fabsf(c[i].z), fabsf(c[i].w))));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m2 = fmaxf(m2, fmaxf(fmaxf(fabsf(b[i].x), fabsf(b[i].y)), fmaxf(fabsf(b[i].z), fabsf(b[i].w))));
+  }
+  {
+    // column L1 norms (what bounds a row of the transposed products): four threads per column, a quarter of the
+    // rows each, combined through LDS in fixed order
+    __shared__ float colp[2][4][256];
+    const int col = tid & 255, part = tid >> 8;
     float a = 0.f, b = 0.f;
-    for (int f = 0; f < 64; ++f) a += fabsf(w3[f * 256 + tid]);
-    for (int k = 0; k < 256; ++k) b += fabsf(w2[k * 256 + tid]);
-    r3 = a; r2 = b;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) a += fabsf(w3[(16 * part + f) * 256 + col]);
+#pragma unroll 16
+    for (int k = 0; k < 64; ++k) b += fabsf(w2[(64 * part + k) * 256 + col]);
+    colp[0][part][col] = a; colp[1][part][col] = b;
+    __syncthreads();
+    if (tid < 256) {
+      r3 = (colp[0][0][tid] + colp[0][1][tid]) + (colp[0][2][tid] + colp[0][3][tid]);
+      r2 = (colp[1][0][tid] + colp[1][1][tid]) + (colp[1][2][tid] + colp[1][3][tid]);
+    }
   }
   float v[5] = {m1, m2, m3, r3, r2};
 #pragma unroll
@@ -860,6 +900,10 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
 // ------------------------------------------------------------------------------------------------------------
 bool ff3_fused_ok(const rpde_ff_params* p, long P) {
   if (const char* e = getenv("RPDE_FUSED_FF")) if (e[0] == '0') return false;
+  // (the preparation kernels read the weight matrices 16 bytes at a time: a view with an odd storage offset takes the
+  //  per-GEMM path)
+  for (int l = 0; l < 3 && p->weights; ++l)
+    if (reinterpret_cast<uintptr_t>(p->weights[l]) & 15) return false;
   return p->n_layers == 3 && p->dim == 64 && p->factor == 4 && P >= 32;
 }
 size_t ff3_fused_ws_floats() { return (FF_IMG_BYTES + FF_NCONST * 4 + 3) / 4; }

@@ -288,3 +288,38 @@ def test_small_channel_conv_kernel(gpu_device, cin, cout, act_in, act_out):
     for name, a_, m_, r_ in zip(("plain", "accumulate", "eval"), got, gemm, refs):
         assert _rel(a_, r_) < 2e-6, (name, _rel(a_, r_))
         assert _rel(m_, r_) < 2e-6, (name, "gemm", _rel(m_, r_))
+
+
+@pytest.mark.parametrize("shape", [(9, 64, 64, 20), (8, 128, 128, 12), (5, 64, 64, 16), (2, 64, 64, 24), (3, 128, 64, 8),
+                                   (1, 192, 192, 20), (17, 64, 64, 4), (2, 256, 256, 20)])
+def test_round3_spectral_kernels_over_batch_grid_and_mode_variants(gpu_device, shape):
+    """the round-3 kernels (k_dft_analysis_sq_h2: XCD groups with uneven sample counts, grids of 64 .. 256; k_mix_h2 /
+    k_mix_wgrad_h2: every (K32, TG) operand layout incl. the packed tails; k_dft_synthesis3_h2: persistent tiles with
+    1 .. many tiles per workgroup, with and without the skip gradient) against the per-GEMM path"""
+    B, M, N, K = shape
+    torch.manual_seed(B * 1000 + M + N + K)
+    x = torch.randn(B, M, N, 64, device=gpu_device)
+    x = x * torch.logspace(-3, 3, B, device=gpu_device).view(B, 1, 1, 1)          # samples of very different magnitude
+    wy = torch.randn(64, 64, K, 2, device=gpu_device) * 0.1
+    wx = torch.randn(64, 64, K, 2, device=gpu_device) * 0.1
+    g = torch.randn(B, M, N, 64, device=gpu_device)
+
+    def run():
+        from rpde import ops
+        xs = x.clone().requires_grad_(True)
+        a, b = wy.clone().requires_grad_(True), wx.clone().requires_grad_(True)
+        out, skip = ops.fspectral2d(xs, a, b, K, with_skip=True)
+        (out * g + skip * (0.5 * g)).sum().backward()          # the skip gradient is added by the adjoint synthesis
+        return out.detach(), xs.grad, a.grad, b.grad
+
+    fused = run()
+    with _env(RPDE_FUSED_SPECTRAL="0"):
+        plain = run()
+    for name, p, q in zip(("out", "dx", "dWy", "dWx"), fused, plain):
+        assert torch.isfinite(p).all(), name
+        # per sample for the fields (a sample 1e6 smaller than its neighbour must keep its own accuracy)
+        if name in ("out", "dx"):
+            worst = max(_rel(p[i], q[i]) for i in range(B))
+            assert worst < 3e-6, (name, worst)
+        else:
+            assert _rel(p, q) < 3e-6, (name, _rel(p, q))
