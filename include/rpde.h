@@ -148,6 +148,15 @@ int rpde_fspectral2d_bwd(const float* grad_out, const float* spec_y, const float
                          float* grad_x, float* grad_wy, float* grad_wx, const float* grad_skip,
                          int B, int M, int N, int C, int K, int mode,
                          void* ws, size_t ws_bytes, void* stream);
+/* The same for FSpectralConv2d.forward_fourier in evaluation: rpde_fspectral2d_prep_bytes (0: nothing to prepare for
+ * this shape, use rpde_fspectral2d_fwd) bytes hold the mode-mix weight fragments of both axes; the forward then needs
+ * rpde_fspectral2d_eval_ws_bytes of workspace (the spectra live there: nothing is saved for a backward). */
+size_t rpde_fspectral2d_prep_bytes(int M, int N, int C, int K);
+size_t rpde_fspectral2d_eval_ws_bytes(int B, int M, int N, int C, int K);
+int rpde_fspectral2d_prepare(const float* w_y, const float* w_x, int M, int N, int C, int K,
+                             void* prep, size_t prep_bytes, void* stream);
+int rpde_fspectral2d_fwd_prepared(const float* x, const void* prep, float* out, int B, int M, int N, int C, int K,
+                                  void* ws, size_t ws_bytes, void* stream);
 
 /* ---- SpectralConv1d.forward  (models/spectral_convolution.py:38-55)
  * x [B,Cin,n] channels-first, w [Cin,Cout,K] complex64 (interleaved floats),
@@ -219,6 +228,13 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
                          float* const* grad_weights, float* const* grad_biases,
                          float* grad_gamma, float* grad_beta, int64_t P,
                          void* ws, size_t ws_bytes, void* stream);
+/* Evaluation with frozen weights (rollouts, all-resolution sweeps, validation): the fused kernel's weight fragments are
+ * built once by rpde_feedforward_prepare into a caller-owned buffer of rpde_feedforward_fwd_ws_bytes bytes and reused
+ * by rpde_feedforward_fwd_prepared until the caller knows the weights have changed.  Fused shapes only
+ * (rpde_feedforward_is_fused); dropout_p must be 0. */
+int rpde_feedforward_prepare(const rpde_ff_params* p, void* prep, size_t prep_bytes, void* stream);
+int rpde_feedforward_fwd_prepared(const rpde_ff_params* p, const float* x, const float* residual, float* out, int64_t P,
+                                  const void* prep, size_t prep_bytes, void* stream);
 
 /* ---- pointwise linear, channels-last: nn.Linear / WNLinear applied to
  * [P,in] (models/ffno.py:113,121,225,233; custom_layer.py:70).  Weight-norm is

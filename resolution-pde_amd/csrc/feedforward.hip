@@ -185,6 +185,25 @@ int rpde_feedforward_is_fused(int dim, int factor, int n_layers, int64_t P) {
   return ff3_fused_ok(&q, (long)P) ? 1 : 0;
 }
 
+// ---- evaluation with frozen weights: the weight fragments of the fused kernel are built once (rpde_feedforward_prepare)
+// and reused by every call until the weights change (rpde.ops.frozen_weights owns that promise) ----
+int rpde_feedforward_prepare(const rpde_ff_params* p, void* prep, size_t prep_bytes, void* stream) {
+  RPDE_CHECK_ARG(p && prep, "feedforward_prepare: bad arguments");
+  RPDE_CHECK_ARG(ff3_fused_ok(p, 32) && prep_bytes >= arena_bytes(ff3_fused_ws_floats()), "feedforward_prepare: shape not fused or buffer too small");
+  RPDE_CHECK_ARG(p->weights && p->weights[0] && p->weights[1] && p->weights[2], "feedforward_prepare: null weights");
+  return ff3_fused_prepare(p, prep, as_stream(stream));
+}
+
+int rpde_feedforward_fwd_prepared(const rpde_ff_params* p, const float* x, const float* residual, float* out, int64_t P,
+                                  const void* prep, size_t prep_bytes, void* stream) {
+  RPDE_CHECK_ARG(p && x && out && prep && P > 0 && P < (1L << 31), "feedforward_fwd_prepared: bad arguments");
+  RPDE_CHECK_ARG(ff3_fused_ok(p, P) && prep_bytes >= arena_bytes(ff3_fused_ws_floats()), "feedforward_fwd_prepared: shape not fused");
+  RPDE_CHECK_ARG(!p->layer_norm || (p->ln_gamma && p->ln_beta), "feedforward_fwd_prepared: layer_norm needs gamma/beta");
+  RPDE_CHECK_ARG(p->dropout_p == 0.f, "feedforward_fwd_prepared: evaluation only");
+  return ff3_fused_fwd(p, x, residual, nullptr, nullptr, out /* z_last is not written in evaluation */, out, P,
+                       const_cast<void*>(prep), as_stream(stream), true);
+}
+
 int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs,
                          float* const* ds, float* z_last, float* out, int64_t P, void* ws, size_t ws_bytes, void* stream) {
   RPDE_CHECK_ARG(p && x && z_last && out && P > 0, "feedforward_fwd: bad arguments");

@@ -9,8 +9,10 @@ size_t ff3_fused_ws_floats();
 // hs and ds with all four buffers: training, h1, d1, h2, d2 and z_last are stored for rpde_feedforward_bwd;
 // hs only (ds null): training in recompute mode, hs receive u = dropout(z) of the hidden layers and the backward
 // re-evaluates gelu / gelu' from them; neither: evaluation, only `out` is written
+// prepared: ws already holds ff3_fused_prepare's output for these weights (evaluation with frozen weights)
+int ff3_fused_prepare(const rpde_ff_params* p, void* ws, hipStream_t st);
 int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs, float* const* ds,
-                  float* z_last, float* out, long P, void* ws, hipStream_t st);
+                  float* z_last, float* out, long P, void* ws, hipStream_t st, bool prepared = false);
 // backward: everything except the three weight-gradient GEMMs (feedforward.hip runs those on dz3 / du2 / du1)
 constexpr int FF3_PART = 704;            // per workgroup: db1[256] db2[256] db3[64] dgamma[64] dbeta[64]
 size_t ff3_fused_bwd_part_floats();

@@ -908,15 +908,26 @@ bool ff3_fused_ok(const rpde_ff_params* p, long P) {
 }
 size_t ff3_fused_ws_floats() { return (FF_IMG_BYTES + FF_NCONST * 4 + 3) / 4; }
 
+// the weight image + constants of the forward kernel (ff3_fused_ws_floats() floats at ws)
+int ff3_fused_prepare(const rpde_ff_params* p, void* ws, hipStream_t st) {
+  char* img = static_cast<char*>(ws);
+  float* consts = reinterpret_cast<float*>(img + FF_IMG_BYTES);
+  const float* b1 = p->biases ? p->biases[0] : nullptr;
+  const float* b2 = p->biases ? p->biases[1] : nullptr;
+  hipLaunchKernelGGL(k_ff3_prep, dim3(FF_PREP_BLOCKS), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], b1, b2, img, consts);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+// prepared: ws already holds what ff3_fused_prepare wrote for these weights (evaluation with frozen weights)
 int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual, float* const* hs, float* const* ds,
-                  float* z_last, float* out, long P, void* ws, hipStream_t st) {
+                  float* z_last, float* out, long P, void* ws, hipStream_t st, bool prepared) {
   char* img = static_cast<char*>(ws);
   float* consts = reinterpret_cast<float*>(img + FF_IMG_BYTES);
   const float* b1 = p->biases ? p->biases[0] : nullptr;
   const float* b2 = p->biases ? p->biases[1] : nullptr;
   const float* b3 = p->biases ? p->biases[2] : nullptr;
-  hipLaunchKernelGGL(k_ff3_prep, dim3(FF_PREP_BLOCKS), dim3(1024), 0, st, p->weights[0], p->weights[1], p->weights[2], b1, b2, img, consts);
-  RPDE_LAUNCH_CHECK();
+  if (!prepared) RPDE_TRY(ff3_fused_prepare(p, ws, st));
   FF3P A;
   memset(&A, 0, sizeof(A));
   const bool have_h = hs && hs[0] && hs[1], have_d = ds && ds[0] && ds[1];

@@ -205,8 +205,10 @@ static size_t fused2d_ws(const Axis& ay, const Axis& ax, int C, bool backward) {
   return n;
 }
 
+// prep (optional): weight fragments + constants written by rpde_fspectral2d_prepare for these weights
 static int fused2d_fwd(const Axis& ay, const Axis& ax, const float* x, const float* w_y, const float* w_x, float* out,
-                       float* spec_y, float* spec_x, int B, int M, int N, int C, int K, int mode, Arena& ar, hipStream_t st) {
+                       float* spec_y, float* spec_x, int B, int M, int N, int C, int K, int mode, Arena& ar, hipStream_t st,
+                       const void* prep = nullptr) {
   float* wblk = ar.take((size_t)ay.keff * 4 * C * C);
   const size_t sy = spec_floats(ay, C), sx = spec_floats(ax, C);
   float* mixed = ar.take(sy > sx ? sy : sx);
@@ -222,7 +224,12 @@ static int fused2d_fwd(const Axis& ay, const Axis& ax, const float* x, const flo
   if (!ar.ok()) { set_error("fspectral2d: workspace too small"); return RPDE_ERR_WORKSPACE; }
   if (mode == RPDE_MODE_FULL && fused_mix_on()) {
     // prep (weights -> fragments) | analysis (+ max per line) | mix (spectra -> operand blocks) | synthesis
-    RPDE_TRY(mix_prep(w_y, w_x, K, ay.keff, ay.kp, 0, wimg, wc, st));
+    if (prep) {
+      wimg = const_cast<void*>(prep);
+      wc = reinterpret_cast<float*>(static_cast<char*>(wimg) + arena_bytes(mix_wimg_bytes(ay.kp) / 4));
+    } else {
+      RPDE_TRY(mix_prep(w_y, w_x, K, ay.keff, ay.kp, 0, wimg, wc, st));
+    }
     RPDE_TRY(fused2d_analysis(x, spec_y, spec_x, amy, amx, ay.plan, ax.plan, 0, B, M, N, st));
     RPDE_TRY(mix_h2(spec_y, spec_x, amy, amx, imgy, imgx, invy, invx, ay.rows, ax.rows, ay.kp, wimg, wc, st));
     return fused2d_synthesis(imgy, imgx, invy, invx, ay.plan, ax.plan, 0, out, nullptr, B, M, N, st);
@@ -391,6 +398,48 @@ int rpde_fspectral2d_fwd(const float* x, const float* w_y, const float* w_x, flo
   }
   Arena ar(ws, ws_bytes);
   return axis_fwd(ay, x, w_y, K, out, spec_y, C, mode, 1, ar, st);
+}
+
+// ---- evaluation with frozen weights: rpde_fspectral2d_prepare builds the mode-mix weight fragments once,
+// rpde_fspectral2d_fwd_prepared runs analysis | mix | synthesis with them; spectra live in the workspace ----
+size_t rpde_fspectral2d_prep_bytes(int M, int N, int C, int K) {
+  Axis ay, ax;
+  axis_dims(ay, N, K, M);
+  axis_dims(ax, M, K, N);
+  if (!fused2d_ok(M, N, C, ay.keff, ax.keff) || !fused_mix_on()) return 0;      // 0: this shape has nothing to prepare
+  return arena_bytes(mix_wimg_bytes(ay.kp) / 4) + arena_bytes(4 * (size_t)ay.kp);
+}
+
+size_t rpde_fspectral2d_eval_ws_bytes(int B, int M, int N, int C, int K) {
+  return rpde_fspectral2d_ws_bytes(B, M, N, C, K) + arena_bytes(rpde_fspectral2d_spec_elems(B, M, N, C, K, 0)) +
+         arena_bytes(rpde_fspectral2d_spec_elems(B, M, N, C, K, 1));
+}
+
+int rpde_fspectral2d_prepare(const float* w_y, const float* w_x, int M, int N, int C, int K, void* prep, size_t prep_bytes,
+                             void* stream) {
+  RPDE_CHECK_ARG(w_y && w_x && prep && M > 0 && N > 0 && K > 0, "fspectral2d_prepare: bad arguments");
+  const size_t need = rpde_fspectral2d_prep_bytes(M, N, C, K);
+  RPDE_CHECK_ARG(need > 0 && prep_bytes >= need, "fspectral2d_prepare: shape not on the fused path or buffer too small");
+  Axis ay;
+  axis_dims(ay, N, K, M);
+  float* wc = reinterpret_cast<float*>(static_cast<char*>(prep) + arena_bytes(mix_wimg_bytes(ay.kp) / 4));
+  return mix_prep(w_y, w_x, K, ay.keff, ay.kp, 0, prep, wc, as_stream(stream));
+}
+
+int rpde_fspectral2d_fwd_prepared(const float* x, const void* prep, float* out, int B, int M, int N, int C, int K, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(x && prep && out && ws && B > 0 && M > 0 && N > 0 && C > 0 && K > 0, "fspectral2d_fwd_prepared: bad arguments");
+  RPDE_CHECK_ARG(rpde_fspectral2d_prep_bytes(M, N, C, K) > 0, "fspectral2d_fwd_prepared: shape not on the fused path");
+  hipStream_t st = as_stream(stream);
+  Axis ay, ax;
+  RPDE_TRY(make_axis(ay, N, K, RPDE_NORM_ORTHO, B * M, 1, (long)N * C, 0, C, st));
+  RPDE_TRY(make_axis(ax, M, K, RPDE_NORM_ORTHO, B * N, N, (long)M * N * C, C, (long)N * C, st));
+  Arena ar(ws, ws_bytes);
+  float* spec_y = ar.take(rpde_fspectral2d_spec_elems(B, M, N, C, K, 0));
+  float* spec_x = ar.take(rpde_fspectral2d_spec_elems(B, M, N, C, K, 1));
+  if (!ar.ok()) { set_error("fspectral2d_fwd_prepared: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  Arena rest(static_cast<char*>(ws) + ar.used, ws_bytes - ar.used);
+  return fused2d_fwd(ay, ax, x, nullptr, nullptr, out, spec_y, spec_x, B, M, N, C, K, RPDE_MODE_FULL, rest, st, prep);
 }
 
 int rpde_fspectral2d_bwd(const float* grad_out, const float* spec_y, const float* spec_x, const float* w_y, const float* w_x,

@@ -112,9 +112,6 @@ __global__ __launch_bounds__(TL_THREADS) void k_thin_outer(const float* __restri
   float acc[T][4], cs[4] = {0.f, 0.f, 0.f, 0.f}, ts[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) { ts[t] = 0.f; acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f; }
-  // (eight points' loads in flight per thread: one 256-thread workgroup per CU has nothing else to hide their latency
-  //  with -- measured 282 -> see profiles/ for 537 MB at 2 M points)
-#pragma unroll 8
   for (long p = p0 + pl; p < p1; p += pps) {
     const float4 v = *reinterpret_cast<const float4*>(b + p * O + 4 * og);
     cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w;
@@ -208,30 +205,34 @@ int thin_contract(const float* a, const float* w, long ws_t, long ws_o, const fl
   return RPDE_OK;
 }
 
-// at least 128 points per workgroup (a sweep of 256 threads covers 4 .. 64 of them), at most 256 workgroups: the
-// fold that follows is a handful of workgroups reading every slab (1024 slabs made it 65 us at 2 M points)
+// at least 128 points per workgroup (a sweep of 256 threads covers 4 .. 64 of them), at most 1024 workgroups = four per
+// CU: with one (four waves per CU, one 16-byte load in flight per thread) the kernel ran at 1.8 TB/s, bound by load
+// latency.  (Round 2 capped this at 256 because the fold over 1024 slabs took 65 us: the fold is now spread over sixteen
+// slab groups per output.)
 static int tl_outer_blocks(long P) {
   long nb = (P + 127) / 128;
-  if (nb > 256) nb = 256;
+  if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
 size_t thin_outer_ws_floats(long P, int T, int O) { return (size_t)tl_outer_blocks(P) * ((T + 1) * O + 4); }
 
-// slabs [nb][(T + 1) * O + 4] -> G (as [T][O], or transposed [O][T]), cs [O], ts [T]; 64 outputs per workgroup, the four
-// waves split the slabs and are combined through LDS in fixed order
+// slabs [nb][(T + 1) * O + 4] -> G (as [T][O], or transposed [O][T]), cs [O], ts [T]; 16 outputs per workgroup, sixteen
+// groups of threads split the slabs and are combined through LDS in fixed order
 __global__ __launch_bounds__(256) void k_thin_fold(const float* __restrict__ slabs, int nb, int T, int O, float* __restrict__ G,
                                                    int g_transposed, float* __restrict__ cs, float* __restrict__ ts) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, n = (T + 1) * O + T, stride = (T + 1) * O + 4;
-  const int e = blockIdx.x * 64 + tx;
+  __shared__ float red[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, n = (T + 1) * O + T, stride = (T + 1) * O + 4;
+  const int e = blockIdx.x * 16 + tx;
   float acc = 0.f;
   if (e < n)
-    for (int s = ty; s < nb; s += 4) acc += slabs[(long)s * stride + e];
+    for (int s = ty; s < nb; s += 16) acc += slabs[(long)s * stride + e];
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && e < n) {
-    acc = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += red[j][tx];
     if (e < T * O) {
       if (G) { const int t = e / O, o = e % O; G[g_transposed ? o * T + t : e] = acc; }
     } else if (e < (T + 1) * O) {
@@ -257,7 +258,7 @@ int thin_outer(const float* a, const float* b, float* G, int g_transposed, float
   }
   RPDE_LAUNCH_CHECK();
   const int n = (T + 1) * O + T;
-  hipLaunchKernelGGL(k_thin_fold, dim3((n + 63) / 64), dim3(256), 0, st, ws, nb, T, O, G, g_transposed, cs, ts);
+  hipLaunchKernelGGL(k_thin_fold, dim3((n + 15) / 16), dim3(256), 0, st, ws, nb, T, O, G, g_transposed, cs, ts);
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;
 }

@@ -94,6 +94,12 @@ _SIGNATURES = {
     "rpde_feedforward_is_fused": (_I, [_I, _I, _I, _L]),
     "rpde_feedforward_fwd": (_I, [C.POINTER(FFParams), _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
     "rpde_feedforward_bwd": (_I, [C.POINTER(FFParams), _P, _PP, _PP, _P, _P, _P, _PP, _PP, _P, _P, _L, _P, _Z, _P]),
+    "rpde_feedforward_prepare": (_I, [C.POINTER(FFParams), _P, _Z, _P]),
+    "rpde_feedforward_fwd_prepared": (_I, [C.POINTER(FFParams), _P, _P, _P, _L, _P, _Z, _P]),
+    "rpde_fspectral2d_prep_bytes": (_Z, [_I, _I, _I, _I]),
+    "rpde_fspectral2d_eval_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "rpde_fspectral2d_prepare": (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "rpde_fspectral2d_fwd_prepared": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_linear_ws_bytes": (_Z, [_L, _I, _I]),
     "rpde_linear_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
     "rpde_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _Z, _P]),

@@ -7,6 +7,7 @@ librpde_hip.so.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import ctypes as C
@@ -28,6 +29,46 @@ def _as_float_storage(w: torch.Tensor) -> torch.Tensor:
     """complex64 [..] -> float32 [..,2] view of the same memory"""
     w = w if w.is_contiguous() else w.contiguous()
     return torch.view_as_real(w) if w.is_complex() else w
+
+
+# ----------------------------------------------------------------------------
+# frozen weights: evaluation loops (validation, all-resolution sweeps, rollouts -- reference train/training.py:78-123,
+# utils/autoregressive_step.py) call the same layers hundreds of times with weights nobody touches.  Inside
+# ``with frozen_weights():`` the no-grad paths of the FeedForward and of the 2-D spectral layer build their weight
+# fragments (weight-norm / f16 pieces / mode-mix B operands) ONCE per layer and reuse them; the scope's end drops them.
+# Contract: inside the scope the weights are changed, if at all, by torch in-place ops (which bump ``_version`` and
+# refresh the entry) -- not by a kernel writing through a raw pointer (FlatAdamW.step: do not step inside the scope).
+# ----------------------------------------------------------------------------
+_FROZEN: Optional[dict] = None
+
+
+@contextlib.contextmanager
+def frozen_weights():
+    global _FROZEN
+    outer = _FROZEN
+    if outer is None:
+        _FROZEN = {}
+    try:
+        yield
+    finally:
+        if outer is None:
+            _FROZEN = None
+
+
+def _frozen_entry(kind, tensors, extra, nbytes, build):
+    """prepared buffer for these weight tensors, built by build(buf) on first use; None when no scope is open (or while
+    a HIP graph is being captured: a graph must not hold a pointer whose life ends with the scope)"""
+    if _FROZEN is None or torch.cuda.is_current_stream_capturing():
+        return None
+    key = (kind, extra) + tuple(t.data_ptr() for t in tensors)
+    ver = tuple(t._version for t in tensors)
+    hit = _FROZEN.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    buf = hit[1] if hit is not None else torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device)
+    build(buf)
+    _FROZEN[key] = (ver, buf, tensors)          # (the tensors are held so that no data_ptr can be reused by another)
+    return buf
 
 
 # ----------------------------------------------------------------------------
@@ -120,6 +161,29 @@ class _FSpectral2d(torch.autograd.Function):
         return gx, gwy, gwx, None, None, None
 
 
+def _fspectral2d_frozen(x, wy, wx, modes: int):
+    """evaluation inside frozen_weights(): rpde_fspectral2d_prepare once per layer, then rpde_fspectral2d_fwd_prepared
+    (the spectra live in the workspace: nothing is kept for a backward).  None: this shape has nothing to prepare."""
+    lib = load()
+    x = _f32c(x)
+    B, M, N, Cc = x.shape
+    npre = lib.rpde_fspectral2d_prep_bytes(M, N, Cc, modes)
+    if npre == 0:
+        return None
+    wyf, wxf = _f32c(wy), _f32c(wx)
+    prep = _frozen_entry("fs2d", (wyf, wxf), (M, N, Cc, modes), npre, lambda buf: check(
+        lib.rpde_fspectral2d_prepare(ptr(wyf), ptr(wxf), M, N, Cc, modes, buf.data_ptr(), npre, stream_ptr()),
+        "fspectral2d_prepare"))
+    if prep is None:
+        return None
+    out = torch.empty_like(x)
+    nws = lib.rpde_fspectral2d_eval_ws_bytes(B, M, N, Cc, modes)
+    ws = workspace(nws, x.device)
+    check(lib.rpde_fspectral2d_fwd_prepared(ptr(x), prep.data_ptr(), ptr(out), B, M, N, Cc, modes, ws.data_ptr(), nws,
+                                            stream_ptr()), "fspectral2d_fwd_prepared")
+    return out
+
+
 def fspectral1d(x, w, modes: int, mode: str = "full", norm: str = "ortho", with_skip: bool = False):
     """FSpectralConv1d.forward_fourier: x [B,n,C], w [C,C,K,2].
     with_skip: returns (out, x') where x' aliases x -- use x' for a skip connection around the layer and
@@ -135,6 +199,10 @@ def fspectral2d(x, wy, wx, modes: int, mode: str = "full", with_skip: bool = Fal
         # the reference's 2-D layer has no else branch: both spectra stay zero
         return (torch.zeros_like(x), x) if with_skip else torch.zeros_like(x)
     full = mode == "full"
+    if full and _FROZEN is not None and not torch.is_grad_enabled() and x.is_cuda:
+        out = _fspectral2d_frozen(x, wy, wx, int(modes))
+        if out is not None:
+            return (out, x) if with_skip else out
     return _FSpectral2d.apply(x, wy if full else None, wx if full else None, int(modes), MODE[mode], bool(with_skip))
 
 
@@ -169,12 +237,21 @@ class _FeedForward(torch.autograd.Function):
         hs = [None if lean else torch.empty(P, hid, dtype=torch.float32, device=x.device) for _ in range(L - 1)]
         ds = [torch.empty(P, hid, dtype=torch.float32, device=x.device) if (need_grad and not recompute) else None
               for _ in range(L - 1)]
-        z_last = torch.empty(P, dim, dtype=torch.float32, device=x.device)
         out = torch.empty(P, dim, dtype=torch.float32, device=x.device)
+        # (the pre-LayerNorm tensor is saved for backward only: the evaluation kernel does not write it)
+        z_last = out if lean else torch.empty(P, dim, dtype=torch.float32, device=x.device)
         wa, ba, ha, da = ptr_array(ws_), ptr_array(bs_), ptr_array(hs or [None]), ptr_array(ds or [None])
         fp = _lib.FFParams(L, dim, factor, int(layer_norm), eps, p_drop, seed, post_act,
                            C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta))
         nws = lib.rpde_feedforward_fwd_ws_bytes(dim, factor, L)
+        if lean and p_drop == 0.0:
+            held = tuple(ws_ + bs_ + ([gamma, beta] if layer_norm else []))
+            prep = _frozen_entry("ff", held, (L, dim, factor), nws, lambda buf: check(
+                lib.rpde_feedforward_prepare(C.byref(fp), buf.data_ptr(), nws, stream_ptr()), "feedforward_prepare"))
+            if prep is not None:
+                check(lib.rpde_feedforward_fwd_prepared(C.byref(fp), ptr(x2), ptr(res2), ptr(out), P, prep.data_ptr(), nws,
+                                                        stream_ptr()), "feedforward_fwd_prepared")
+                return out.reshape(shape)
         ws = workspace(nws, x.device)
         check(lib.rpde_feedforward_fwd(C.byref(fp), ptr(x2), ptr(res2), C.cast(ha, C.POINTER(C.c_void_p)),
                                        C.cast(da, C.POINTER(C.c_void_p)), ptr(z_last), ptr(out), P, ws.data_ptr(), nws,

@@ -21,6 +21,7 @@ from typing import Callable, Optional
 import torch
 import torch.distributed as dist
 
+from rpde.ops import frozen_weights
 from rpde.parallel import FlatGradBucket
 from utils.loss import RelativeL2Loss
 
@@ -74,7 +75,7 @@ def train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=No
         model.eval()
         vrun = torch.zeros((), device=device)
         vn = 0
-        with torch.no_grad():
+        with torch.no_grad(), frozen_weights():      # the weights rest until the next epoch: prepare them once
             for val_x, val_y in val_loader:
                 val_x, val_y = val_x.to(device), val_y.to(device)
                 val_pred = model(val_x)
@@ -116,7 +117,7 @@ def evaluate(model, test_loader,
     total = torch.zeros((), device=device)
     n = 0
     warned = False
-    with torch.no_grad():
+    with torch.no_grad(), frozen_weights():
         for x, y in test_loader:
             x, y = x.to(device), y.to(device)
             pred = model(x)

@@ -9,6 +9,7 @@ from typing import Optional
 
 import torch
 
+from rpde.ops import frozen_weights
 from utils.loss import RelativeL2Loss
 
 
@@ -29,12 +30,17 @@ def _rollout(model, state, steps, x_normalizer, y_normalizer, device):
     x-statistics (autoregressive_step.py:296-303).  With global statistics both maps are affine, so the pair is ONE
     multiply-add  state = pred * (s_y / s_x) + (m_y - m_x) / s_x  -- a single pass over the field instead of four;
     point-wise normalisers keep the two calls."""
-    preds = []
     fused = None
     if x_normalizer is not None and y_normalizer is not None:
         sx, sy = _scalar_stats(x_normalizer), _scalar_stats(y_normalizer)
         if sx is not None and sy is not None:
             fused = (sy[1] / sx[1], torch.full((), (sy[0] - sx[0]) / sx[1], device=state.device, dtype=state.dtype))
+    with frozen_weights():                                     # one weight preparation for all steps
+        return _rollout_steps(model, state, steps, x_normalizer, y_normalizer, device, fused)
+
+
+def _rollout_steps(model, state, steps, x_normalizer, y_normalizer, device, fused):
+    preds = []
     for _ in range(steps):
         nxt = model(state.unsqueeze(1))                        # [B,1,*S] in, [B,1,*S] out
         if nxt.shape[1] == 1:

@@ -55,15 +55,17 @@ def evaluate_all_resolutions(model, test_x: torch.Tensor, test_y: torch.Tensor, 
     mine_x, mine_y = test_x[rank::world], test_y[rank::world]
     resolutions = get_lower_resolutions(max_resolution or full, min_resolution)
     acc = torch.zeros(len(resolutions), 2, dtype=torch.float64, device=device)
-    for k, res in enumerate(resolutions):
-        for i in range(0, mine_x.shape[0], batch_size):
-            x = to_resolution(mine_x[i:i + batch_size].to(device), res, how)
-            y = to_resolution(mine_y[i:i + batch_size].to(device), res, how)
-            pred = model(x_encode(x) if x_encode else x)
-            if y_decode:
-                pred = y_decode(pred)
-            acc[k, 0] += loss_fn(pred, y).double() * x.shape[0]
-            acc[k, 1] += x.shape[0]
+    from rpde.ops import frozen_weights
+    with frozen_weights():                      # one weight preparation per layer (and grid) for the whole sweep
+        for k, res in enumerate(resolutions):
+            for i in range(0, mine_x.shape[0], batch_size):
+                x = to_resolution(mine_x[i:i + batch_size].to(device), res, how)
+                y = to_resolution(mine_y[i:i + batch_size].to(device), res, how)
+                pred = model(x_encode(x) if x_encode else x)
+                if y_decode:
+                    pred = y_decode(pred)
+                acc[k, 0] += loss_fn(pred, y).double() * x.shape[0]
+                acc[k, 1] += x.shape[0]
     if on:
         dist.all_reduce(acc)
     acc = acc.cpu()
