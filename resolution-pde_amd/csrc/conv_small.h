@@ -12,4 +12,9 @@ int conv1x1_small(const float* x, const float* w, const float* bias, float* out,
 bool conv1x1_syn_ok(const float* x, const float* out, int Cin, int Cout, int M, int N);
 int conv1x1_syn(const float* x, const float* w, const float* bias, const float* t, const float* fs_t, float* out, int B, int Cin,
                 int Cout, int M, int N, int R2, int act_out, hipStream_t st);
+// the same on the matrix pipe (conv_syn_h2.hip): N in {64,128,256,512}, Cin = 32, Cout <= 32, R2 a multiple of 8
+// up to 32; RPDE_CONV_SYN_H2=0 keeps the fp32 multiply-add kernel
+bool conv_syn_h2_ok(const float* x, const float* out, const float* t, int Cin, int Cout, int M, int N, int R2);
+int conv_syn_h2(const float* x, const float* w, const float* bias, const float* t, const float* fs_t, float* out, int B, int Cin,
+                int Cout, int M, int N, int R2, int act_out, hipStream_t st);
 }  // namespace rpde

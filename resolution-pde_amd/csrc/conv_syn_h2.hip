@@ -1,0 +1,322 @@
+// Tail of the evaluation-mode FNO block on the matrix pipe (reference: models/fno_blocks.py:63-83,
+// activation(spectral_conv(x) + bypass_conv(x)) on channels-first fields):
+//
+//   out[b][o][m][n] = act( bias[o] + sum_i W[o][i] x[b][i][m][n] + sum_r t[b][o][m][r] Fs[r][n] )
+//
+// For one row (b, m) this is ONE product  [W | t_bm] (Cout x (Cin + R2))  .  [x_bm ; Fs] ((Cin + R2) x N)  whose
+// left factor changes with the row only in its last R2 columns and whose right factor changes only in its first Cin
+// rows.  k_conv1x1_small<.., true> (conv_small.hip) evaluates it with fp32 multiply-adds fed from LDS broadcasts: at
+// width 32 that is 1792 multiply-adds per point against 256 B of traffic, and the vector ALU and the LDS return path
+// saturate together at about half the HBM rate (363 us per block at 512^2, B = 16: 2.96 TB/s).  Here both halves run as
+// h2 products (h2.h: three f16 MFMAs, fp32-class accuracy):
+//
+//   * a workgroup of 8 waves takes 8 * 64 / N rows at a time; a wave owns 64 consecutive points of a row for the whole
+//     launch, so its four column tiles of the synthesis table stay in registers as ready B fragments, as do the
+//     W fragments (A operand: rows = output channels);
+//   * per row the wave reads its [Cin x 64] slab of x with 16-byte loads (256 contiguous bytes per channel), scales by
+//     the slab maximum, splits into f16 pieces, stages them in its private 8 KB of LDS and fetches B fragments with
+//     transposing reads -- the analysis kernels' staging (fused_spectral.hip), with channels in the place of points;
+//   * the row's spectra t_bm (3 KB) become A fragments in registers: second accumulator, its own scale;
+//   * bias, activation, then the [Cout x 64] result goes through the same LDS area so that the stores are 256-byte
+//     runs per channel like the loads.
+// No workgroup barrier.  A row's slab of x is requested one whole row ahead (two register buffers; the table fragments
+// live in LDS to make room for them).
+#include "conv_small.h"
+#include "h2.h"
+
+#include <stdlib.h>
+
+namespace rpde {
+
+// offset of 4 consecutive f16 (columns 4 c8 ..) of row k in a [32][64] f16 tile with 128-byte rows, XOR-swizzled so
+// that the transposing reads below spread over all banks (the layout of fused_spectral.hip's staging area)
+__device__ __forceinline__ int cs_stage_off(int k, int c8) {
+  return k * 128 + ((c8 ^ ((((k >> 1) & 1) << 2) | (((k >> 3) & 1) << 3))) << 3);
+}
+
+// LDS stores the compiler does not see as such: with an LDS-DMA in flight it would put s_waitcnt vmcnt(0) in front of
+// every ordinary ds_write (it cannot tell that the DMA's landing area and the staging area are disjoint) and so drain
+// the prefetch.  A wave's DS instructions execute in order, so later reads of the same wave see these without a wait.
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cs_lds_addr(const void* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void cs_lds_write_b64(unsigned addr, uint2 v) {
+  const u32x2v t = {v.x, v.y};
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(t) : "memory");
+}
+__device__ __forceinline__ void cs_lds_write_b32(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// The transposing read likewise (the builtin carries no memory operand, so with a DMA in flight the compiler waits for
+// vmcnt(0) in front of it): issued as asm, completed by cs_lds_wait4 on the four results.
+template <int OFF>
+__device__ __forceinline__ u32x2v cs_lds_read_tr16(unsigned addr) {
+  u32x2v r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+__device__ __forceinline__ void cs_lds_wait4(u32x2v& a, u32x2v& b, u32x2v& c, u32x2v& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+// ... and the 16-byte reads of the output staging
+__device__ __forceinline__ f32x4v cs_lds_read_b128(unsigned addr) {
+  f32x4v r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+__device__ __forceinline__ void cs_lds_wait8(f32x4v (&v)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+}
+
+template <int N>
+__device__ __forceinline__ void cs_wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Cin = 32, R2 <= 32.  ACT: the activation; FULL: Cout = 32 (no predicate on the stores)
+//
+// Memory queue discipline.  gfx950 has ONE in-order counter (vmcnt) for loads, stores and LDS-DMA, and the compiler,
+// seeing ordinary loads and stores in flight together, waits for zero -- which would drain the next row's prefetch and
+// this row's stores at every use.  So both inputs of a row (its slab of x: 8 KB, its spectra: 4 KB) come by LDS-DMA
+// (global_load_lds: no register result, nothing for the compiler to wait on) into per-wave landing areas, and the
+// kernel counts itself: at the top of a row the queue holds [12 DMA pieces of this row][8 stores of the previous row],
+// so vmcnt(8) means "my inputs have landed" while the stores drain on their own.  The landing areas are free again as
+// soon as the row has been converted (a few hundred cycles into it), and the next row's DMA is issued right there.
+template <int ACT, bool FULL>
+__global__ __launch_bounds__(512) void k_conv_syn_h2(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const float* __restrict__ t,
+                                                     const float* __restrict__ fs_t, float* __restrict__ out, int B, int Cout,
+                                                     int M, int N, int R2) {
+  constexpr int CIN = 32, RAW = 8192, TRAW = 4096, STG = 8192, WAVE_LDS = RAW + TRAW + STG;     // 20 KB x 8 waves = all of LDS
+  __shared__ __attribute__((aligned(16))) char smem[8 * WAVE_LDS];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = l >> 4, li = l & 15;
+  char* const raw = smem + wave * WAVE_LDS;
+  char* const traw = raw + RAW;
+  char* const stage = traw + TRAW;
+  const unsigned stage_a = cs_lds_addr(stage), raw_a = cs_lds_addr(raw);
+  const int q = li >> 2, pp = li & 3;
+  const int tsw = ((q >> 1) & 1) | ((g & 1) << 1);
+  const int trow = (8 * g + q) * 128 + pp * 8;
+
+  const int nw = N >> 6, rpi = 8 / nw;                 // waves per row, rows per pass of the workgroup
+  const int n0 = 64 * (wave % nw), wrow = wave / nw;
+  const long MN = (long)M * N;
+  const int rows = B * M;                              // (host: B * M < 2^30; 32-bit row arithmetic stays uniform and branch-free)
+
+  // ---- resident operands ----
+  float wsc, winv;
+  {
+    float m = 0.f;
+    for (int e = l; e < Cout * CIN; e += 64) m = fmaxf(m, fabsf(w[e]));
+    h2_scale(wave_max(m), 0, wsc, winv);
+  }
+  f16x8 wh[2], wl[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int o = 16 * mt + li;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = o < Cout ? w[o * CIN + 8 * g + j] * wsc : 0.f;
+    union { f16x8 v; struct { uint2 a, b; } u; } H, L;
+    h2_split4(v[0], v[1], v[2], v[3], H.u.a, L.u.a);
+    h2_split4(v[4], v[5], v[6], v[7], H.u.b, L.u.b);
+    wh[mt] = H.v; wl[mt] = L.v;
+  }
+  f16x8 fh[4], fl[4];
+  float finv;
+  {
+    float fv[4][8], m = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * g + j;
+        fv[nt][j] = r < R2 ? fs_t[(long)r * N + n0 + 16 * nt + li] : 0.f;
+        m = fmaxf(m, fabsf(fv[nt][j]));
+      }
+    float fsc;
+    h2_scale(wave_max(m), 0, fsc, finv);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      union { f16x8 v; struct { uint2 a, b; } u; } H, L;
+      h2_split4(fv[nt][0] * fsc, fv[nt][1] * fsc, fv[nt][2] * fsc, fv[nt][3] * fsc, H.u.a, L.u.a);
+      h2_split4(fv[nt][4] * fsc, fv[nt][5] * fsc, fv[nt][6] * fsc, fv[nt][7] * fsc, H.u.b, L.u.b);
+      fh[nt] = H.v; fl[nt] = L.v;
+    }
+  }
+  float bb[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = 16 * mt + 4 * g + j;
+      bb[mt][j] = (bias && o < Cout) ? bias[o] : 0.f;
+    }
+  // spectra of a row as A fragments: lane (g, li) holds t[o = 16 mt + li][r = 8 g .. 8 g + 7]; out-of-range lanes fetch
+  // a clamped address and are masked when the fragment is built
+  bool tok[2];
+  long toff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int o = 16 * mt + li, r0 = 8 * g;
+    tok[mt] = o < Cout && r0 < R2;
+    toff[mt] = (long)min(o, Cout - 1) * M * R2 + min(r0, R2 - 8);
+  }
+  cs_wait_vmcnt<0>();                                  // (the prologue's loads: from here on the queue is counted by hand)
+
+  // 12 DMA pieces of 1 KB: x slab piece i = channels 4 i + g, points n0 + 4 li .. + 3; spectra piece (mt, h)
+  auto issue = [&](int r) {
+    r = r < rows ? r : rows - 1;                       // (past the end: a harmless re-read, never used)
+    const long b = r / M, m = r % M;
+    const float* px = x + (b * CIN * M + m) * N + n0 + 4 * li;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(px + (long)(4 * i + g) * MN), (lds_ptr)(raw + i * 1024), 16, 0, 0);
+    const float* pt0 = t + (b * Cout * M + m) * R2;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(pt0 + toff[mt] + 4 * h), (lds_ptr)(traw + (mt * 2 + h) * 1024), 16, 0, 0);
+  };
+  const int stride = (int)gridDim.x * rpi;
+  int r = (int)blockIdx.x * rpi + wrow;
+  issue(r);
+  bool first = true;
+  for (; r < rows; r += stride) {
+    const long b = r / M, m = r % M;
+    // this row's 12 pieces are in; the previous row's 8 stores may still be out (a predicated store that no lane takes is
+    // not issued at all, so without FULL the count is unknown and the queue is drained)
+    if (first || !FULL) cs_wait_vmcnt<0>(); else cs_wait_vmcnt<8>();
+    first = false;
+    // ---- x slab -> scaled f16 pieces in the staging area; spectra -> A fragments ----
+    // (asm reads: an ordinary LDS load of a DMA's landing area makes the compiler wait for vmcnt(0), stores included)
+    f32x4v xb[8], tq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xb[i] = cs_lds_read_b128(raw_a + i * 1024 + l * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tq[i] = cs_lds_read_b128(raw_a + RAW + i * 1024 + l * 16);
+#pragma unroll
+    for (int i = 4; i < 8; ++i) tq[i] = tq[0];
+    cs_lds_wait8(xb);
+    cs_lds_wait8(tq);
+    f32x4v (&tb)[2][2] = *reinterpret_cast<f32x4v (*)[2][2]>(&tq[0]);
+    issue(r + stride);                                            // next row's pieces in flight under this row's work
+    float mx = 0.f, mtv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xb[i].x), fabsf(xb[i].y)), fmaxf(fabsf(xb[i].z), fabsf(xb[i].w))));
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        mtv = fmaxf(mtv, fmaxf(fmaxf(fabsf(tb[mt][h].x), fabsf(tb[mt][h].y)), fmaxf(fabsf(tb[mt][h].z), fabsf(tb[mt][h].w))));
+    float xsc, xinv, tsc, tinv;
+    h2_scale(wave_max(mx), 0, xsc, xinv);
+    h2_scale(wave_max(mtv), 0, tsc, tinv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint2 hi, lo;
+      h2_split4(xb[i].x * xsc, xb[i].y * xsc, xb[i].z * xsc, xb[i].w * xsc, hi, lo);
+      const int off = cs_stage_off(4 * i + g, li);
+      cs_lds_write_b64(stage_a + off, hi);
+      cs_lds_write_b64(stage_a + 4096 + off, lo);
+    }
+    f16x8 th[2], tl[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float ts = tok[mt] ? tsc : 0.f;
+      union { f16x8 v; struct { uint2 a, b; } u; } H, L;
+      h2_split4(tb[mt][0].x * ts, tb[mt][0].y * ts, tb[mt][0].z * ts, tb[mt][0].w * ts, H.u.a, L.u.a);
+      h2_split4(tb[mt][1].x * ts, tb[mt][1].y * ts, tb[mt][1].z * ts, tb[mt][1].w * ts, H.u.b, L.u.b);
+      th[mt] = H.v; tl[mt] = L.v;
+    }
+    wave_lds_fence();
+    f32x4v a1[2][4], a2[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) a1[mt][nt] = a2[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const unsigned ts = stage_a + trow + ((nt ^ tsw) << 5);
+      union { struct { u32x2v a, b; } h; f16x8 v; } bh, bl;
+      bh.h.a = cs_lds_read_tr16<0>(ts);
+      bh.h.b = cs_lds_read_tr16<512>(ts);
+      bl.h.a = cs_lds_read_tr16<4096>(ts);
+      bl.h.b = cs_lds_read_tr16<4096 + 512>(ts);
+      cs_lds_wait4(bh.h.a, bh.h.b, bl.h.a, bl.h.b);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        a1[mt][nt] = h2_mfma32(wh[mt], wl[mt], bh.v, bl.v, a1[mt][nt]);
+        a2[mt][nt] = h2_mfma32(th[mt], tl[mt], fh[nt], fl[nt], a2[mt][nt]);
+      }
+    }
+    wave_lds_fence();
+    // bias, activation; through LDS ([32 channels][64 points] fp32, 16-byte pieces XOR-swizzled by the row group) so that
+    // a lane ends up with four consecutive points of one channel
+    const float i1 = xinv * winv, i2 = tinv * finv;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = fmaf(a1[mt][nt][j], i1, fmaf(a2[mt][nt][j], i2, bb[mt][j]));
+          v = act_f(ACT, v);
+          const int row = 16 * mt + 4 * g + j;
+          cs_lds_write_b32(stage_a + row * 256 + (((4 * nt + (li >> 2)) ^ (g << 2)) << 4) + (li & 3) * 4, v);
+        }
+    wave_lds_fence();
+    float* po = out + (b * Cout * M + m) * N + n0 + 4 * li;
+    f32x4v ov[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ov[i] = cs_lds_read_b128(stage_a + (4 * i + g) * 256 + ((li ^ ((i & 3) << 2)) << 4));
+    cs_lds_wait8(ov);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + g;
+      // FULL: exactly 8 store instructions per row -- the count above depends on it
+      if (FULL || row < Cout) *reinterpret_cast<f32x4v*>(po + (long)row * MN) = ov[i];
+    }
+    wave_lds_fence();
+  }
+  cs_wait_vmcnt<0>();                                  // (the last issue() ran past the end: let it land before the LDS is released)
+}
+
+bool conv_syn_h2_ok(const float* x, const float* out, const float* t, int Cin, int Cout, int M, int N, int R2) {
+  if (const char* e = getenv("RPDE_CONV_SYN_H2")) if (e[0] == '0') return false;
+  const bool nok = N == 64 || N == 128 || N == 256 || N == 512;
+  // (the templates for Cin = 64 / R2 > 32 exist but spill registers: the multiply-add kernel keeps those shapes)
+  return nok && (long)M < (1L << 20) && Cin == 32 && Cout >= 1 && Cout <= 32 && R2 >= 8 && R2 <= 32 && R2 % 8 == 0 && M >= 1 &&
+         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(t)) & 15) == 0;
+}
+
+int conv_syn_h2(const float* x, const float* w, const float* bias, const float* t, const float* fs_t, float* out, int B, int Cin,
+                int Cout, int M, int N, int R2, int act_out, hipStream_t st) {
+  int dev = 0, cus = 256;
+  RPDE_HIP(hipGetDevice(&dev));
+  RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int rpi = 8 / (N / 64);
+  long grid = ((long)B * M + rpi - 1) / rpi;
+  if (grid > cus) grid = cus;
+  if (Cin != 32 || R2 > 32 || (long)B * M >= (1L << 30)) { set_error("conv_syn_h2: shape not covered"); return RPDE_ERR_ARG; }
+  const dim3 gd((unsigned)grid), bk(512);
+#define RPDE_CS_LAUNCH(ACT, FULL) \
+  hipLaunchKernelGGL((k_conv_syn_h2<ACT, FULL>), gd, bk, 0, st, x, w, bias, t, fs_t, out, B, Cout, M, N, R2)
+  const bool full = Cout == 32;
+  if (act_out == RPDE_ACT_GELU) { if (full) RPDE_CS_LAUNCH(RPDE_ACT_GELU, true); else RPDE_CS_LAUNCH(RPDE_ACT_GELU, false); }
+  else if (act_out == RPDE_ACT_RELU) { if (full) RPDE_CS_LAUNCH(RPDE_ACT_RELU, true); else RPDE_CS_LAUNCH(RPDE_ACT_RELU, false); }
+  else { if (full) RPDE_CS_LAUNCH(RPDE_ACT_IDENTITY, true); else RPDE_CS_LAUNCH(RPDE_ACT_IDENTITY, false); }
+#undef RPDE_CS_LAUNCH
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+}  // namespace rpde

@@ -400,6 +400,8 @@ int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, c
   MixGeom g{B, Cin, Cout, R, m1, m2, kp};
   RPDE_TRY(launch_mix(0, s2, nullptr, w1, w2, o2, nullptr, g, st));
   RPDE_TRY(cf_rowdft(pm->fs, 2L * R, false, 2 * M, 2 * R, o2, t1, B * Cout, kp, st));
+  if (conv_syn_h2_ok(x, out, t1, Cin, Cout, M, N, 2 * kp))
+    return conv_syn_h2(x, wc, bc, t1, pn->fs_t, out, B, Cin, Cout, M, N, 2 * kp, act_out, st);
   return conv1x1_syn(x, wc, bc, t1, pn->fs_t, out, B, Cin, Cout, M, N, 2 * kp, act_out, st);
 }
 

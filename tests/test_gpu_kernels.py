@@ -5,6 +5,7 @@ torch reference is right for a floating-point kernel); the DFT plan tables with
 the float64 restatement in oracle/dft_math.py; the dropout masks of the three
 places that regenerate them with each other."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -378,11 +379,14 @@ def test_fused_projection_mlp_matches_float64(gpu_device, shape, act_in):
             os.environ["RPDE_CONV_MLP"] = old
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64, 12, 12), (1, 8, 6, 48, 256, 5, 9), (2, 4, 4, 16, 1024, 3, 4)])
+# (width-32 shapes with N in {64..512} take the matrix-pipe tail k_conv_syn_h2, the others k_conv1x1_small<.., true>)
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64, 12, 12), (1, 8, 6, 48, 256, 5, 9), (2, 4, 4, 16, 1024, 3, 4),
+                                   (1, 32, 32, 40, 512, 12, 12), (3, 32, 20, 33, 128, 6, 8), (2, 32, 32, 7, 256, 4, 16),
+                                   (5, 32, 9, 3, 64, 2, 3)])
 @pytest.mark.parametrize("act", ["gelu", "relu"])
 def test_fused_evaluation_fnoblock2d_equals_the_two_step_path(gpu_device, shape, act):
-    """rpde_fnoblock2d_eval_fwd (conv_small.hip SYN): act(SpectralConv2d(x) + bypass(x)) in one pass against the
-    spectral op followed by the accumulating convolution, and against float64"""
+    """rpde_fnoblock2d_eval_fwd (conv_syn_h2.hip / conv_small.hip SYN): act(SpectralConv2d(x) + bypass(x)) in one pass
+    against the spectral op followed by the accumulating convolution, and against float64"""
     from rpde import ops
     B, Ci, Co, M, N, m1, m2 = shape
     torch.manual_seed(M + N + Ci)
@@ -404,3 +408,18 @@ def test_fused_evaluation_fnoblock2d_equals_the_two_step_path(gpu_device, shape,
         ref = torch.nn.functional.gelu(pre) if act == "gelu" else torch.relu(pre)
     assert float((got.cpu().double() - ref).norm() / ref.norm()) < 2e-6
     assert float((got - two).norm() / two.norm()) < 2e-6
+    # samples / rows of very different magnitude: the per-slab scales of the matrix-pipe tail must not leak
+    xs = x * torch.logspace(-3, 3, M, device=gpu_device).view(1, 1, M, 1)
+    old = os.environ.get("RPDE_CONV_SYN_H2")
+    with torch.no_grad():
+        a = ops.fnoblock2d_eval(xs, w1, w2, wc, bc, act)
+        os.environ["RPDE_CONV_SYN_H2"] = "0"
+        try:
+            b_ = ops.fnoblock2d_eval(xs, w1, w2, wc, bc, act)
+        finally:
+            if old is None:
+                os.environ.pop("RPDE_CONV_SYN_H2")
+            else:
+                os.environ["RPDE_CONV_SYN_H2"] = old
+    rows = (a - b_).flatten(0, 1).transpose(0, 1).flatten(1).norm(dim=1) / b_.flatten(0, 1).transpose(0, 1).flatten(1).norm(dim=1).clamp_min(1e-30)
+    assert float(rows.max()) < 5e-6, float(rows.max())
