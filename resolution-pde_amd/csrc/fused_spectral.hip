@@ -382,28 +382,48 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
     __syncthreads();
   }
   const long rowf = (long)n * 64;                   // floats per row of the field
-  auto issue_x = [&](float4 (&buf)[8], long u) {    // column gw, rows of block t: lane (g, li) takes rows 4i + g
-    if (!has_x || u >= units) return;
+  // The field comes through registers, one unit ahead -- by loads the compiler does not see (asm) and waits counted by
+  // hand.  Left to the compiler every use of a prefetched chunk is preceded by s_waitcnt vmcnt(0..7): it takes the
+  // chunk for the youngest thing in flight, so each phase also waits for the OTHER axis's chunk, requested only a
+  // phase ago, and for the spectrum stores in between -- the prefetch distance shrinks from a unit to nothing (this
+  // kernel ran at 219 us, latency-bound).  The queue is in order: behind the x chunk of unit u there are always the 8
+  // loads of the y chunk of u (and some stores), behind the y chunk of u the 8 loads of the x chunk of u + 1; so
+  // vmcnt(8) is enough in both places.  Every wave with a duty issues exactly 8 loads per phase (past the end: a
+  // clamped re-read), so the count holds; a wave with only one duty waits for zero.
+  auto gload = [](const float* p) {
+    f32x4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  };
+  auto issue_x = [&](f32x4v (&buf)[8], long u) {    // column gw, rows of block t: lane (g, li) takes rows 4i + g
+    if (!has_x) return;
+    u = u < units ? u : units - 1;
     const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
     const float* q0 = P.x + (((long)(xg + P.ng * sb) * n + 32 * t + g) * n + gw) * 64 + li * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) buf[i] = *reinterpret_cast<const float4*>(q0 + i * 4 * rowf);
+    for (int i = 0; i < 8; ++i) buf[i] = gload(q0 + i * 4 * rowf);
   };
-  auto issue_y = [&](float4 (&buf)[8], long u) {    // row 32 t + jw, points 32 wave ..: lane (g, li) takes points 4i + g
-    if (!has_y || u >= units) return;
+  auto issue_y = [&](f32x4v (&buf)[8], long u) {    // row 32 t + jw, points 32 wave ..: lane (g, li) takes points 4i + g
+    if (!has_y) return;
+    u = u < units ? u : units - 1;
     const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
     const float* q0 = P.x + (((long)(xg + P.ng * sb) * n + 32 * t + jw) * n + 32 * wave + g) * 64 + li * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) buf[i] = *reinterpret_cast<const float4*>(q0 + i * 256);
+    for (int i = 0; i < 8; ++i) buf[i] = gload(q0 + i * 256);
+  };
+  // the chunk in buf has landed once at most `younger` later vector-memory instructions are outstanding
+  auto landed = [&](f32x4v (&buf)[8], bool other_duty) {
+    if (other_duty)
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])::"memory");
   };
   // one 32-point chunk into accumulators that stay in scaled units for the whole line (k_dft_analysis_h2's scheme)
-  auto process = [&](float4 (&buf)[8], int s, f32x4v (&tot)[MT][4], int& line_E) {
+  auto process = [&](f32x4v (&buf)[8], int s, f32x4v (&tot)[MT][4], int& line_E) {
     float m = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(buf[i].x), "v"(buf[i].y));
-      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(buf[i].z), "v"(buf[i].w));
-    }
+    for (int i = 0; i < 8; ++i)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(buf[i].x), fabsf(buf[i].y)), fmaxf(fabsf(buf[i].z), fabsf(buf[i].w))));
     m = wave_max(m);
     {
       const int E = max((int)(__float_as_uint(m) >> 23) & 0xff, 15 + H2_TABLE_EXP);
@@ -452,45 +472,17 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
 
   f32x4v totx[MT][4], toty[MT][4];
   int Ex = 0;
-  float4 bx[8], by[8];
-  issue_x(bx, 0);
+  f32x4v bx[8], by[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bx[i] = by[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the table copy above: from here on the queue is counted by hand)
   issue_y(by, 0);
+  issue_x(bx, 0);
   for (long u = 0; u < units; ++u) {
     const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
     const int b = xg + P.ng * sb;
-    // ---- x axis: this wave's column, rows of block t ----
-    if (has_x) {
-      if (t == 0) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) totx[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-        Ex = 0;
-      }
-      process(bx, t, totx, Ex);
-      issue_x(bx, u + 1);
-      mfma_chunk(t, totx);
-      if (t == steps - 1) {
-        const long z = (long)b * n + gw;
-        float* __restrict__ sp = P.spec_x + z * (long)P.R * 64;
-        const float inv = __uint_as_float((unsigned)(Ex - 14 - H2_TABLE_EXP) << 23);
-        float am = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int row = 16 * mt + 4 * g + j;
-            if (row < P.R) {
-#pragma unroll
-              for (int nt = 0; nt < 4; ++nt) sp[row * 64 + 16 * nt + li] = totx[mt][nt][j] * inv;
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) am = fmaxf(am, fabsf(totx[mt][nt][j]));
-          }
-        am = wave_max(am);
-        if (l == 0 && P.amax_x) P.amax_x[z] = am * inv;
-      }
-    }
+    // (y first: its loads -- whole rows, 64 KB contiguous per workgroup, 2 MB per group -- are then the ones that go
+    //  to HBM, and the x axis's 256-byte pieces, requested a phase later, find the rows in the L2)
     // ---- y axis: row 32 t + jw of the block; this wave's chunk of it, then the sum over the chunks ----
     float invy = 0.f;
     if (has_y) {
@@ -499,6 +491,7 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) toty[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
       int Ey = 0;
+      landed(by, has_x);
       process(by, wave, toty, Ey);
       issue_y(by, u + 1);
       mfma_chunk(wave, toty);
@@ -543,6 +536,40 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
       float a8 = 0.f;
       for (int i = 0; i < ANA_WAVES; ++i) a8 = fmaxf(a8, wmax[i]);
       P.amax_y[zy] = a8;
+    }
+    // ---- x axis: this wave's column, rows of block t ----
+    if (has_x) {
+      if (t == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) totx[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        Ex = 0;
+      }
+      landed(bx, has_y);
+      process(bx, t, totx, Ex);
+      issue_x(bx, u + 1);
+      mfma_chunk(t, totx);
+      if (t == steps - 1) {
+        const long z = (long)b * n + gw;
+        float* __restrict__ sp = P.spec_x + z * (long)P.R * 64;
+        const float inv = __uint_as_float((unsigned)(Ex - 14 - H2_TABLE_EXP) << 23);
+        float am = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = 16 * mt + 4 * g + j;
+            if (row < P.R) {
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) sp[row * 64 + 16 * nt + li] = totx[mt][nt][j] * inv;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) am = fmaxf(am, fabsf(totx[mt][nt][j]));
+          }
+        am = wave_max(am);
+        if (l == 0 && P.amax_x) P.amax_x[z] = am * inv;
+      }
     }
   }
 }

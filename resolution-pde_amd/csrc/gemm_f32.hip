@@ -53,10 +53,12 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
     if (bm == 32) { BMc = 32; BNc = 128; }
     else if (bn == 32) { BMc = 128; BNc = 32; }
     else { BMc = bm; BNc = bn; }
-    // small problems (the 1-D configurations): 128x128 tiles would leave most of the 256 CUs idle
+    // small problems (the 1-D configurations): 128x128 tiles would leave most of the 256 CUs idle, or give each just
+    // one four-wave workgroup (FFNO1D at B = 16: 256 tiles; 64x64 tiles: 1.50 -> 1.44 ms per step under a HIP graph)
     static const bool small_tiles = [] { const char* e = getenv("RPDE_SMALL_TILES"); return !(e && e[0] == '0'); }();
+    static const long small_below = [] { const char* e = getenv("RPDE_SMALL_TILES_BELOW"); return e ? atol(e) : 384L; }();
     if (small_tiles && BMc == 128 && BNc == 128 && !d.colsum &&
-        (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit < 128) { BMc = 64; BNc = 64; }
+        (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit < small_below) { BMc = 64; BNc = 64; }
   }
   g.mtiles = (d.M + BMc - 1) / BMc;
   g.ntiles = (d.N + BNc - 1) / BNc;
