@@ -165,6 +165,10 @@ static int build_plan(rpde_plan** out, int n, int modes, int norm, int planar, i
     const int t = R * n;
     hipLaunchKernelGGL(k_cplx_analysis, dim3((t + 255) / 256), dim3(256), 0, st, p->fa, n, modes, bot, sf);
     hipLaunchKernelGGL(k_cplx_synthesis, dim3((t + 255) / 256), dim3(256), 0, st, p->fs, n, modes, bot, si);
+    // fs transposed, [2R, 2n]: read along the output index by k_col_mix_synthesis (spectral_cf.hip)
+    RPDE_HIP(hipMalloc(&p->fs_t, sizeof(float) * 2 * n * 2 * R));
+    const int tt = 2 * n * 2 * R;
+    hipLaunchKernelGGL(k_transpose_small, dim3((tt + 255) / 256), dim3(256), 0, st, p->fs, p->fs_t, 2 * n, 2 * R);
   }
   RPDE_LAUNCH_CHECK();
   *out = p;

@@ -11,7 +11,8 @@ struct rpde_plan {
   int ldn;      // leading dim of fa: real: n rounded up to 4;  complex: 2n
   float* fa;    // real: [2kp, ldn] analysis;     complex: [2R, 2n]
   float* fs;    // real: [n, 2kp] synthesis;      complex: [2n, 2R]
-  float* fs_t;  // real planar plans: fs transposed, [2kp, n] (read 16 bytes per lane along n by conv_small.hip)
+  float* fs_t;  // fs transposed: real planar plans [2kp, n] (read along n by conv_small.hip / conv_syn_h2.hip),
+                // complex plans [2R, 2n] (read along the output index by spectral_cf.hip's column stage)
   // real, interleaved plans: the tables pre-split for the split-bf16 GEMM (gemm_bf16x3.hip), as A operands:
   // [IMG_FA] Fa (2kp x n), [IMG_FST] Fs^T (2kp x n), [IMG_FS] Fs (n x 2kp), [IMG_FAT] Fa^T (n x 2kp)
   void* img[4];

@@ -259,6 +259,172 @@ static int cf_rowdft(const float* table, long ld_table, bool transpose, int m_ou
   return launch_gemm(d, st);
 }
 
+// ---- column stage of SpectralConv2d in two launches (evaluation paths) ------------------------------------------
+// Between the two passes over the field the layer touches little data -- at 512^2, width 32, 12 x 12 modes: 1.5 MB of row
+// spectra per sample in, 74 KB of retained modes, 1.5 MB out -- but as generic GEMMs with a 12-wide free dimension the
+// three steps (column DFT, mode mix, inverse column DFT) took 62 + 28 + 39 us per block at B = 16: latency, not work.
+// Plain fp32 multiply-adds, shaped to the data instead:
+//   k_col_analysis       one workgroup per (b, c): the [2M, kp] block of row spectra is staged in LDS once; a wave owns
+//                        rows rho, rho + 4, .. of the [2R, 2M] table, lanes run along the reduction index (coalesced table
+//                        reads), kp accumulators per lane, one wave-wide sum per row.
+//   k_col_mix_synthesis  one workgroup per (b, o): the mode mix of compl_mul2d (reference spectral_convolution.py:75-77)
+//                        for this output channel into LDS (2R x kp values), then a thread per output row (m, re | im):
+//                        its 2R table entries (contiguous) against the mixed block (LDS broadcasts), kp contiguous results.
+constexpr int COL_THREADS = 256;
+constexpr int COL_MIX_THREADS = 320;
+
+template <int KP>
+__global__ __launch_bounds__(COL_THREADS) void k_col_analysis(const float* __restrict__ fa, const float* __restrict__ s1,
+                                                              float* __restrict__ s2, int M2, int R2) {
+  extern __shared__ __attribute__((aligned(16))) float col_sm[];
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  const long bc = blockIdx.x;
+  {
+    const float4* src = reinterpret_cast<const float4*>(s1 + bc * (long)M2 * KP);
+    float4* dst = reinterpret_cast<float4*>(col_sm);
+    for (int e = tid; e < M2 * KP / 4; e += COL_THREADS) dst[e] = src[e];
+  }
+  __syncthreads();
+  // four table rows at a time: a row of the staged block (kp values from LDS) then feeds 4 kp multiply-adds -- with one
+  // row at a time the kernel was bound by the LDS return path (79 us)
+  for (int rho0 = 4 * wv; rho0 < R2; rho0 += 4 * (COL_THREADS / 64)) {
+    float acc[4][KP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < KP; ++k) acc[j][k] = 0.f;
+    const float* __restrict__ frow = fa + (long)rho0 * M2;
+    // (R2 = 4 m1: always whole groups of four rows)
+#pragma unroll 2
+    for (int mu = l; mu < M2; mu += 64) {
+      float f[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = frow[(long)j * M2 + mu];
+      const float4* row = reinterpret_cast<const float4*>(col_sm + mu * KP);
+#pragma unroll
+      for (int q = 0; q < KP / 4; ++q) {
+        const float4 v = row[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j][4 * q] = fmaf(f[j], v.x, acc[j][4 * q]); acc[j][4 * q + 1] = fmaf(f[j], v.y, acc[j][4 * q + 1]);
+          acc[j][4 * q + 2] = fmaf(f[j], v.z, acc[j][4 * q + 2]); acc[j][4 * q + 3] = fmaf(f[j], v.w, acc[j][4 * q + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float mine = 0.f;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const float t = wave_sum_dpp(acc[j][k]);
+        if (l == k) mine = t;
+      }
+      if (l < KP) s2[(bc * R2 + rho0 + j) * KP + l] = mine;
+    }
+  }
+}
+
+template <int KP>
+__global__ __launch_bounds__(COL_MIX_THREADS) void k_col_mix_synthesis(const float* __restrict__ s2, const float* __restrict__ w1,
+                                                                   const float* __restrict__ w2, const float* __restrict__ fs_t,
+                                                                   float* __restrict__ t1, MixGeom g, int M2) {
+  extern __shared__ __attribute__((aligned(16))) float col_sm[];       // mixed block [2R][KP]
+  const int tid = threadIdx.x, nth = blockDim.x;      // (320 threads when R kp <= 320: the mix in one pass)
+  const long bo = blockIdx.x;
+  const int b = (int)(bo / g.Co), o = (int)(bo % g.Co), R2 = 2 * g.R;
+  const long blk = (long)R2 * KP;
+  for (int e = tid; e < g.R * KP; e += nth) {
+    const int r = e / KP, ky = e % KP;
+    float ar = 0.f, ai = 0.f;
+    if (ky < g.m2) {
+      const float* sp = s2 + (long)b * g.Ci * blk + (2L * r) * KP + ky;
+#pragma unroll 16
+      for (int i = 0; i < g.Ci; ++i) {
+        const float* w = wsel(w1, w2, g, i, o, r, ky);
+        const float wr = w[0], wi = w[1], xr = sp[i * blk], xi = sp[i * blk + KP];
+        ar += xr * wr - xi * wi;
+        ai += xr * wi + xi * wr;
+      }
+    }
+    col_sm[(2 * r) * KP + ky] = ar;
+    col_sm[(2 * r + 1) * KP + ky] = ai;
+  }
+  __syncthreads();
+  // four output rows per thread at a time (mu, mu + 256, ..): a row of the mixed block then feeds 4 kp multiply-adds
+  for (int mu0 = tid; mu0 < M2; mu0 += 4 * nth) {
+    float acc[4][KP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < KP; ++k) acc[j][k] = 0.f;
+    int mus[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mus[j] = min(mu0 + j * nth, M2 - 1);
+    // (table read transposed, [2R][2M]: consecutive lanes = consecutive output rows)
+#pragma unroll 12
+    for (int rho = 0; rho < R2; ++rho) {
+      float f[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = fs_t[(long)rho * M2 + mus[j]];
+      const float4* row = reinterpret_cast<const float4*>(col_sm + rho * KP);
+#pragma unroll
+      for (int q = 0; q < KP / 4; ++q) {
+        const float4 v = row[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j][4 * q] = fmaf(f[j], v.x, acc[j][4 * q]); acc[j][4 * q + 1] = fmaf(f[j], v.y, acc[j][4 * q + 1]);
+          acc[j][4 * q + 2] = fmaf(f[j], v.z, acc[j][4 * q + 2]); acc[j][4 * q + 3] = fmaf(f[j], v.w, acc[j][4 * q + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int mu = mu0 + j * nth;
+      if (mu < M2) {
+        float4* dst = reinterpret_cast<float4*>(t1 + (bo * M2 + mu) * KP);
+#pragma unroll
+        for (int q = 0; q < KP / 4; ++q) dst[q] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+      }
+    }
+  }
+}
+
+// kp in {4, 8, 12, 16}, the staged block within 64 KB, 16-byte aligned workspaces; RPDE_COL_FUSED=0: the three GEMM-shaped steps
+static bool col_stage_ok(int M, int m1, int kp, const float* s1, const float* t1) {
+  if (const char* e = getenv("RPDE_COL_FUSED")) if (e[0] == '0') return false;
+  return kp >= 4 && kp <= 16 && kp % 4 == 0 && (size_t)2 * M * kp * 4 <= 65536 && m1 >= 1 &&
+         ((reinterpret_cast<uintptr_t>(s1) | reinterpret_cast<uintptr_t>(t1)) & 15) == 0;
+}
+
+// s1 [B*Ci][2M][kp] -> s2 [B*Ci][2R][kp] (kept for a backward) -> t1 [B*Co][2M][kp]
+static int col_stage(const rpde_plan* pm, const float* s1, float* s2, const float* w1, const float* w2, float* t1,
+                     const MixGeom& g, int M, hipStream_t st) {
+  const int M2 = 2 * M, R2 = 2 * g.R;
+  const size_t lds_a = sizeof(float) * (size_t)M2 * g.kp, lds_b = sizeof(float) * (size_t)R2 * g.kp;
+  const dim3 ga((unsigned)(g.B * g.Ci)), gb((unsigned)(g.B * g.Co)), bk(COL_THREADS);
+  const dim3 bkm(g.R * g.kp > COL_THREADS ? COL_MIX_THREADS : COL_THREADS);
+  switch (g.kp) {
+    case 4:
+      hipLaunchKernelGGL((k_col_analysis<4>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2);
+      hipLaunchKernelGGL((k_col_mix_synthesis<4>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
+      break;
+    case 8:
+      hipLaunchKernelGGL((k_col_analysis<8>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2);
+      hipLaunchKernelGGL((k_col_mix_synthesis<8>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
+      break;
+    case 12:
+      hipLaunchKernelGGL((k_col_analysis<12>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2);
+      hipLaunchKernelGGL((k_col_mix_synthesis<12>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
+      break;
+    default:
+      hipLaunchKernelGGL((k_col_analysis<16>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2);
+      hipLaunchKernelGGL((k_col_mix_synthesis<16>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
+      break;
+  }
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
 }  // namespace rpde
 
 using namespace rpde;
@@ -353,11 +519,15 @@ int rpde_spectral2d_fwd(const float* x, const float* w1, const float* w2, float*
   float* o2 = ar.take((size_t)B * Cout * 2 * R * kp);
   if (!ar.ok()) { set_error("spectral2d_fwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
   RPDE_TRY(cf_analysis(pn, x, s1, (long)B * Cin * M, N, act_in, st));
-  RPDE_TRY(cf_rowdft(pm->fa, 2L * M, false, 2 * R, 2 * M, s1, spec_in, B * Cin, kp, st));
-  if (kp != m2) RPDE_HIP(hipMemsetAsync(o2, 0, sizeof(float) * (size_t)B * Cout * 2 * R * kp, st));
   MixGeom g{B, Cin, Cout, R, m1, m2, kp};
-  RPDE_TRY(launch_mix(0, spec_in, nullptr, w1, w2, o2, nullptr, g, st));
-  RPDE_TRY(cf_rowdft(pm->fs, 2L * R, false, 2 * M, 2 * R, o2, t1, B * Cout, kp, st));
+  if (col_stage_ok(M, m1, kp, s1, t1)) {
+    RPDE_TRY(col_stage(pm, s1, spec_in, w1, w2, t1, g, M, st));
+  } else {
+    RPDE_TRY(cf_rowdft(pm->fa, 2L * M, false, 2 * R, 2 * M, s1, spec_in, B * Cin, kp, st));
+    if (kp != m2) RPDE_HIP(hipMemsetAsync(o2, 0, sizeof(float) * (size_t)B * Cout * 2 * R * kp, st));
+    RPDE_TRY(launch_mix(0, spec_in, nullptr, w1, w2, o2, nullptr, g, st));
+    RPDE_TRY(cf_rowdft(pm->fs, 2L * R, false, 2 * M, 2 * R, o2, t1, B * Cout, kp, st));
+  }
   return cf_synthesis(pn, t1, out, (long)B * Cout * M, N, st);
 }
 
@@ -395,11 +565,15 @@ int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, c
   float* s2 = ar.take((size_t)B * Cin * 2 * R * kp);
   if (!ar.ok()) { set_error("fnoblock2d_eval_fwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
   RPDE_TRY(cf_analysis(pn, x, s1, (long)B * Cin * M, N, 0, st));
-  RPDE_TRY(cf_rowdft(pm->fa, 2L * M, false, 2 * R, 2 * M, s1, s2, B * Cin, kp, st));
-  if (kp != m2) RPDE_HIP(hipMemsetAsync(o2, 0, sizeof(float) * (size_t)B * Cout * 2 * R * kp, st));
   MixGeom g{B, Cin, Cout, R, m1, m2, kp};
-  RPDE_TRY(launch_mix(0, s2, nullptr, w1, w2, o2, nullptr, g, st));
-  RPDE_TRY(cf_rowdft(pm->fs, 2L * R, false, 2 * M, 2 * R, o2, t1, B * Cout, kp, st));
+  if (col_stage_ok(M, m1, kp, s1, t1)) {
+    RPDE_TRY(col_stage(pm, s1, s2, w1, w2, t1, g, M, st));
+  } else {
+    RPDE_TRY(cf_rowdft(pm->fa, 2L * M, false, 2 * R, 2 * M, s1, s2, B * Cin, kp, st));
+    if (kp != m2) RPDE_HIP(hipMemsetAsync(o2, 0, sizeof(float) * (size_t)B * Cout * 2 * R * kp, st));
+    RPDE_TRY(launch_mix(0, s2, nullptr, w1, w2, o2, nullptr, g, st));
+    RPDE_TRY(cf_rowdft(pm->fs, 2L * R, false, 2 * M, 2 * R, o2, t1, B * Cout, kp, st));
+  }
   if (conv_syn_h2_ok(x, out, t1, Cin, Cout, M, N, 2 * kp))
     return conv_syn_h2(x, wc, bc, t1, pn->fs_t, out, B, Cin, Cout, M, N, 2 * kp, act_out, st);
   return conv1x1_syn(x, wc, bc, t1, pn->fs_t, out, B, Cin, Cout, M, N, 2 * kp, act_out, st);

@@ -408,6 +408,20 @@ def test_fused_evaluation_fnoblock2d_equals_the_two_step_path(gpu_device, shape,
         ref = torch.nn.functional.gelu(pre) if act == "gelu" else torch.relu(pre)
     assert float((got.cpu().double() - ref).norm() / ref.norm()) < 2e-6
     assert float((got - two).norm() / two.norm()) < 2e-6
+    # the column stage (k_col_analysis + k_col_mix_synthesis) against the three GEMM-shaped steps it replaces
+    oldc = os.environ.get("RPDE_COL_FUSED")
+    os.environ["RPDE_COL_FUSED"] = "0"
+    try:
+        with torch.no_grad():
+            gemm_leg = ops.fnoblock2d_eval(x, w1, w2, wc, bc, act)
+            spec_gemm = ops.spectral2d(x, w1, w2)
+    finally:
+        if oldc is None:
+            os.environ.pop("RPDE_COL_FUSED")
+        else:
+            os.environ["RPDE_COL_FUSED"] = oldc
+    assert float((got - gemm_leg).norm() / gemm_leg.norm()) < 2e-6
+    assert float((spec - spec_gemm).norm() / spec_gemm.norm()) < 2e-6
     # samples / rows of very different magnitude: the per-slab scales of the matrix-pipe tail must not leak
     xs = x * torch.logspace(-3, 3, M, device=gpu_device).view(1, 1, M, 1)
     old = os.environ.get("RPDE_CONV_SYN_H2")
