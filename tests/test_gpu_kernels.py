@@ -382,7 +382,7 @@ def test_fused_projection_mlp_matches_float64(gpu_device, shape, act_in):
 # (width-32 shapes with N in {64..512} take the matrix-pipe tail k_conv_syn_h2, the others k_conv1x1_small<.., true>)
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64, 12, 12), (1, 8, 6, 48, 256, 5, 9), (2, 4, 4, 16, 1024, 3, 4),
                                    (1, 32, 32, 40, 512, 12, 12), (3, 32, 20, 33, 128, 6, 8), (2, 32, 32, 7, 256, 4, 16),
-                                   (5, 32, 9, 3, 64, 2, 3)])
+                                   (5, 32, 9, 3, 64, 2, 3), (3, 32, 32, 300, 256, 6, 8), (2, 32, 17, 515, 128, 3, 5)])
 @pytest.mark.parametrize("act", ["gelu", "relu"])
 def test_fused_evaluation_fnoblock2d_equals_the_two_step_path(gpu_device, shape, act):
     """rpde_fnoblock2d_eval_fwd (conv_syn_h2.hip / conv_small.hip SYN): act(SpectralConv2d(x) + bypass(x)) in one pass
