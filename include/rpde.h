@@ -268,6 +268,15 @@ int rpde_fnoblock2d_eval_ok(int Cin, int Cout, int M, int N);
 int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc, float* out,
                              int B, int Cin, int Cout, int M, int N, int m1, int m2, int act_out,
                              void* ws, size_t ws_bytes, void* stream);
+/* FNO2d.forward in evaluation, up to and including the first block (reference models/fno.py:121-147:
+ * cat(x, gridx, gridy) -> lifting -> fno_blocks[0]), without the lifted field ever being written or read:
+ * u [B,1,M,N], gx [M], gy [N] (the grid coordinates, device arrays), wl [C,3], bl [C] (lifting conv), then the block's
+ * parameters as for rpde_fnoblock2d_eval_fwd.  out [B,Cout,M,N]. */
+size_t rpde_fno2d_lift_block_eval_ws_bytes(int B, int C, int Cout, int M, int N, int m1, int m2);
+int rpde_fno2d_lift_block_eval_ok(int Cu, int C, int Cout, int M, int N, int m1, int m2);
+int rpde_fno2d_lift_block_eval_fwd(const float* u, const float* gx, const float* gy, const float* wl, const float* bl,
+                                   const float* w1, const float* w2, const float* wc, const float* bc, float* out, int B, int C,
+                                   int Cout, int M, int N, int m1, int m2, int act_out, void* ws, size_t ws_bytes, void* stream);
 /* the projection MLP mlp2(gelu(mlp1(act_in(x)))) of models/fno_blocks.py:38-45,76-83 in one pass, EVALUATION only
  * (the hidden tensor [B,Cmid,S] is never written; training keeps the two convolutions, whose backward needs it):
  * x [B,Cin,S], w1 [Cmid,Cin], b1 [Cmid], w2 [Cout,Cmid], b2 [Cout], out [B,Cout,S].  rpde_conv_mlp_ok: 1 when the

@@ -15,6 +15,9 @@ int conv1x1_syn(const float* x, const float* w, const float* bias, const float* 
 // the same on the matrix pipe (conv_syn_h2.hip): N in {64,128,256,512}, Cin = 32, Cout <= 32, R2 a multiple of 8
 // up to 32; RPDE_CONV_SYN_H2=0 keeps the fp32 multiply-add kernel
 bool conv_syn_h2_ok(const float* x, const float* out, const float* t, int Cin, int Cout, int M, int N, int R2);
+// lift_u != null: x is not read; the block's input is lifting(cat(u, gx, gy)) with u [B,1,M,N], lift_w [32,3], lift_b [32],
+// gx [M], gy [N] (M <= 1024), formed on the fly
 int conv_syn_h2(const float* x, const float* w, const float* bias, const float* t, const float* fs_t, float* out, int B, int Cin,
-                int Cout, int M, int N, int R2, int act_out, hipStream_t st);
+                int Cout, int M, int N, int R2, int act_out, hipStream_t st, const float* lift_u = nullptr,
+                const float* lift_w = nullptr, const float* lift_b = nullptr, const float* gx = nullptr, const float* gy = nullptr);
 }  // namespace rpde

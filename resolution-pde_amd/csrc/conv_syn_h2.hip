@@ -87,11 +87,26 @@ __device__ __forceinline__ void cs_wait_vmcnt() {
 // kernel counts itself: at the top of a row the queue holds [12 DMA pieces of this row][8 stores of the previous row],
 // so vmcnt(8) means "my inputs have landed" while the stores drain on their own.  The landing areas are free again as
 // soon as the row has been converted (a few hundred cycles into it), and the next row's DMA is issued right there.
-template <int ACT, bool FULL>
+//
+// LIFT: the block's input is the lifting convolution of a ONE-channel field u and the two grid coordinates (reference
+// models/fno.py:121-141: cat(x, gridx, gridy) -> lifting), which is never materialised: a row's slab is formed from 256
+// bytes of u, gx[m] and the wave's four gy values -- x0[c] = wl[c][0] u + wl[c][1] gx + wl[c][2] gy + bl[c] -- so the
+// first block of an FNO2d reads 1/33 of the bytes (the lifted field, 537 MB at 512^2, B = 16, is neither written by a
+// lifting kernel nor read back here).  One DMA piece for u instead of eight; the table of (wl, bl) and gx live in the
+// unused part of the landing area.
+struct CsLift {
+  const float* u;      // [B][1][M][N]
+  const float* wl;     // lifting weight [32][3] (u, gx, gy)
+  const float* bl;     // lifting bias [32] or null
+  const float* gx;     // [M]
+  const float* gy;     // [N]
+};
+
+template <int ACT, bool FULL, bool LIFT>
 __global__ __launch_bounds__(512) void k_conv_syn_h2(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ t,
                                                      const float* __restrict__ fs_t, float* __restrict__ out, int B, int Cout,
-                                                     int M, int N, int R2) {
+                                                     int M, int N, int R2, CsLift L) {
   constexpr int CIN = 32, RAW = 8192, TRAW = 4096, STG = 8192, WAVE_LDS = RAW + TRAW + STG;     // 20 KB x 8 waves = all of LDS
   __shared__ __attribute__((aligned(16))) char smem[8 * WAVE_LDS];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -169,16 +184,31 @@ __global__ __launch_bounds__(512) void k_conv_syn_h2(const float* __restrict__ x
     tok[mt] = o < Cout && r0 < R2;
     toff[mt] = (long)min(o, Cout - 1) * M * R2 + min(r0, R2 - 8);
   }
+  // LIFT: raw + 1024: (wl[c][0..2], bl[c]) for c < 32 (512 B); raw + 2048: gx[0..M) (M <= 1024); this lane's gy values
+  f32x4v gy4 = {0.f, 0.f, 0.f, 0.f};
+  if (LIFT) {
+    if (l < 32) {
+      const f32x4v v = {L.wl[l * 3], L.wl[l * 3 + 1], L.wl[l * 3 + 2], L.bl ? L.bl[l] : 0.f};
+      *reinterpret_cast<f32x4v*>(raw + 1024 + l * 16) = v;
+    }
+    for (int e = l; e < M; e += 64) *reinterpret_cast<float*>(raw + 2048 + e * 4) = L.gx[e];
+    gy4 = *reinterpret_cast<const f32x4v*>(L.gy + n0 + 4 * li);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   cs_wait_vmcnt<0>();                                  // (the prologue's loads: from here on the queue is counted by hand)
 
-  // 12 DMA pieces of 1 KB: x slab piece i = channels 4 i + g, points n0 + 4 li .. + 3; spectra piece (mt, h)
+  // 12 DMA pieces of 1 KB (LIFT: 5): x slab piece i = channels 4 i + g, points n0 + 4 li .. + 3; spectra piece (mt, h)
   auto issue = [&](int r) {
     r = r < rows ? r : rows - 1;                       // (past the end: a harmless re-read, never used)
     const long b = r / M, m = r % M;
-    const float* px = x + (b * CIN * M + m) * N + n0 + 4 * li;
+    if (LIFT) {
+      __builtin_amdgcn_global_load_lds((glb_ptr)(L.u + (b * M + m) * N + n0 + 4 * li), (lds_ptr)(raw), 16, 0, 0);
+    } else {
+      const float* px = x + (b * CIN * M + m) * N + n0 + 4 * li;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr)(px + (long)(4 * i + g) * MN), (lds_ptr)(raw + i * 1024), 16, 0, 0);
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(px + (long)(4 * i + g) * MN), (lds_ptr)(raw + i * 1024), 16, 0, 0);
+    }
     const float* pt0 = t + (b * Cout * M + m) * R2;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -199,14 +229,34 @@ __global__ __launch_bounds__(512) void k_conv_syn_h2(const float* __restrict__ x
     // ---- x slab -> scaled f16 pieces in the staging area; spectra -> A fragments ----
     // (asm reads: an ordinary LDS load of a DMA's landing area makes the compiler wait for vmcnt(0), stores included)
     f32x4v xb[8], tq[8];
+    if (LIFT) {
+      // piece 0: u of this lane's four points; then (wl, bl) of channels 4 i + g; tq[4]: gx[m] (every lane the same)
+      tq[5] = cs_lds_read_b128(raw_a + l * 16);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xb[i] = cs_lds_read_b128(raw_a + i * 1024 + l * 16);
+      for (int i = 0; i < 8; ++i) xb[i] = cs_lds_read_b128(raw_a + 1024 + (4 * i + g) * 16);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xb[i] = cs_lds_read_b128(raw_a + i * 1024 + l * 16);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) tq[i] = cs_lds_read_b128(raw_a + RAW + i * 1024 + l * 16);
-#pragma unroll
-    for (int i = 4; i < 8; ++i) tq[i] = tq[0];
+    if (LIFT) tq[4] = cs_lds_read_b128(raw_a + 2048 + (int)(m & ~3L) * 4); else tq[4] = tq[0];
+    if (!LIFT) tq[5] = tq[0];
+    tq[6] = tq[0]; tq[7] = tq[0];
     cs_lds_wait8(xb);
     cs_lds_wait8(tq);
+    if (LIFT) {
+      const int mm = (int)(m & 3);
+      const float gxm = mm == 0 ? tq[4].x : (mm == 1 ? tq[4].y : (mm == 2 ? tq[4].z : tq[4].w));
+      const f32x4v u4 = tq[5];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4v c = xb[i];                          // (wl_u, wl_gx, wl_gy, bl) of channel 4 i + g
+        const float base = fmaf(c.y, gxm, c.w);
+        xb[i] = (f32x4v){fmaf(c.x, u4.x, fmaf(c.z, gy4.x, base)), fmaf(c.x, u4.y, fmaf(c.z, gy4.y, base)),
+                         fmaf(c.x, u4.z, fmaf(c.z, gy4.z, base)), fmaf(c.x, u4.w, fmaf(c.z, gy4.w, base))};
+      }
+    }
     f32x4v (&tb)[2][2] = *reinterpret_cast<f32x4v (*)[2][2]>(&tq[0]);
     issue(r + stride);                                            // next row's pieces in flight under this row's work
     float mx = 0.f, mtv = 0.f;
@@ -299,7 +349,14 @@ bool conv_syn_h2_ok(const float* x, const float* out, const float* t, int Cin, i
 }
 
 int conv_syn_h2(const float* x, const float* w, const float* bias, const float* t, const float* fs_t, float* out, int B, int Cin,
-                int Cout, int M, int N, int R2, int act_out, hipStream_t st) {
+                int Cout, int M, int N, int R2, int act_out, hipStream_t st, const float* lift_u, const float* lift_w,
+                const float* lift_b, const float* gx, const float* gy) {
+  const bool lift = lift_u != nullptr;
+  CsLift L{lift_u, lift_w, lift_b, gx, gy};
+  if (lift && (!lift_w || !gx || !gy || M > 1024 || (reinterpret_cast<uintptr_t>(lift_u) & 15) || (reinterpret_cast<uintptr_t>(gy) & 15))) {
+    set_error("conv_syn_h2: bad lifting arguments");
+    return RPDE_ERR_ARG;
+  }
   int dev = 0, cus = 256;
   RPDE_HIP(hipGetDevice(&dev));
   RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -309,7 +366,10 @@ int conv_syn_h2(const float* x, const float* w, const float* bias, const float* 
   if (Cin != 32 || R2 > 32 || (long)B * M >= (1L << 30)) { set_error("conv_syn_h2: shape not covered"); return RPDE_ERR_ARG; }
   const dim3 gd((unsigned)grid), bk(512);
 #define RPDE_CS_LAUNCH(ACT, FULL) \
-  hipLaunchKernelGGL((k_conv_syn_h2<ACT, FULL>), gd, bk, 0, st, x, w, bias, t, fs_t, out, B, Cout, M, N, R2)
+  do { \
+    if (lift) hipLaunchKernelGGL((k_conv_syn_h2<ACT, FULL, true>), gd, bk, 0, st, x, w, bias, t, fs_t, out, B, Cout, M, N, R2, L); \
+    else hipLaunchKernelGGL((k_conv_syn_h2<ACT, FULL, false>), gd, bk, 0, st, x, w, bias, t, fs_t, out, B, Cout, M, N, R2, L); \
+  } while (0)
   const bool full = Cout == 32;
   if (act_out == RPDE_ACT_GELU) { if (full) RPDE_CS_LAUNCH(RPDE_ACT_GELU, true); else RPDE_CS_LAUNCH(RPDE_ACT_GELU, false); }
   else if (act_out == RPDE_ACT_RELU) { if (full) RPDE_CS_LAUNCH(RPDE_ACT_RELU, true); else RPDE_CS_LAUNCH(RPDE_ACT_RELU, false); }

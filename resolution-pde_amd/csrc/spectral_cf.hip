@@ -273,13 +273,41 @@ static int cf_rowdft(const float* table, long ld_table, bool transpose, int m_ou
 constexpr int COL_THREADS = 256;
 constexpr int COL_MIX_THREADS = 320;
 
-template <int KP>
+// LIFT (first block of an FNO2d in evaluation, rpde_fno2d_lift_block_eval_fwd): the block's input is the lifting
+// convolution of a one-channel field u and the grid coordinates, x0[c] = wl[c][0] u + wl[c][1] gx[m] + wl[c][2] gy[n] + bl[c].
+// The row DFT is linear, so the row spectra of channel c are
+//   wl[c][0] S_u[b][m] + (wl[c][1] gx[m] + bl[c]) S_1 + wl[c][2] S_gy
+// with S_u the row spectra of u (B M rows instead of B C M), S_1 / S_gy those of the constant row and of gy: they are
+// formed here while the block is staged and never exist in memory.
+struct ColLift {
+  const float* su;     // [B][M][2 kp]
+  const float* sc;     // [2][2 kp]: row spectra of ones(N) and of gy
+  const float* wl;     // [C][3]
+  const float* bl;     // [C] or null
+  const float* gx;     // [M]
+  int C;
+};
+
+template <int KP, bool LIFT>
 __global__ __launch_bounds__(COL_THREADS) void k_col_analysis(const float* __restrict__ fa, const float* __restrict__ s1,
-                                                              float* __restrict__ s2, int M2, int R2) {
+                                                              float* __restrict__ s2, int M2, int R2, ColLift L) {
   extern __shared__ __attribute__((aligned(16))) float col_sm[];
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
   const long bc = blockIdx.x;
-  {
+  if (LIFT) {
+    const int b = (int)(bc / L.C), c = (int)(bc % L.C);
+    const float wu = L.wl[c * 3], wx = L.wl[c * 3 + 1], wy = L.wl[c * 3 + 2], bb = L.bl ? L.bl[c] : 0.f;
+    const float4* src = reinterpret_cast<const float4*>(L.su + (long)b * M2 * KP);      // [M][2 KP] = [2M][KP]
+    float4* dst = reinterpret_cast<float4*>(col_sm);
+    for (int e = tid; e < M2 * KP / 4; e += COL_THREADS) {
+      const int mu = (4 * e) / KP, col = (mu & 1) * KP + (4 * e) % KP;     // (KP % 4 == 0: a float4 stays inside a row)
+      const float4 one = *reinterpret_cast<const float4*>(L.sc + col), gy = *reinterpret_cast<const float4*>(L.sc + 2 * KP + col);
+      const float a = fmaf(wx, L.gx[mu >> 1], bb);
+      const float4 u = src[e];
+      dst[e] = make_float4(fmaf(wu, u.x, fmaf(wy, gy.x, a * one.x)), fmaf(wu, u.y, fmaf(wy, gy.y, a * one.y)),
+                           fmaf(wu, u.z, fmaf(wy, gy.z, a * one.z)), fmaf(wu, u.w, fmaf(wy, gy.w, a * one.w)));
+    }
+  } else {
     const float4* src = reinterpret_cast<const float4*>(s1 + bc * (long)M2 * KP);
     float4* dst = reinterpret_cast<float4*>(col_sm);
     for (int e = tid; e < M2 * KP / 4; e += COL_THREADS) dst[e] = src[e];
@@ -389,6 +417,12 @@ __global__ __launch_bounds__(COL_MIX_THREADS) void k_col_mix_synthesis(const flo
   }
 }
 
+// rows of the constants whose row spectra the lifted block needs: ones(N), gy
+__global__ void k_lift_const_rows(const float* __restrict__ gy, float* __restrict__ out, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { out[i] = 1.f; out[N + i] = gy[i]; }
+}
+
 // kp in {4, 8, 12, 16}, the staged block within 64 KB, 16-byte aligned workspaces; RPDE_COL_FUSED=0: the three GEMM-shaped steps
 static bool col_stage_ok(int M, int m1, int kp, const float* s1, const float* t1) {
   if (const char* e = getenv("RPDE_COL_FUSED")) if (e[0] == '0') return false;
@@ -398,26 +432,30 @@ static bool col_stage_ok(int M, int m1, int kp, const float* s1, const float* t1
 
 // s1 [B*Ci][2M][kp] -> s2 [B*Ci][2R][kp] (kept for a backward) -> t1 [B*Co][2M][kp]
 static int col_stage(const rpde_plan* pm, const float* s1, float* s2, const float* w1, const float* w2, float* t1,
-                     const MixGeom& g, int M, hipStream_t st) {
+                     const MixGeom& g, int M, hipStream_t st, const ColLift* lift = nullptr) {
   const int M2 = 2 * M, R2 = 2 * g.R;
   const size_t lds_a = sizeof(float) * (size_t)M2 * g.kp, lds_b = sizeof(float) * (size_t)R2 * g.kp;
   const dim3 ga((unsigned)(g.B * g.Ci)), gb((unsigned)(g.B * g.Co)), bk(COL_THREADS);
   const dim3 bkm(g.R * g.kp > COL_THREADS ? COL_MIX_THREADS : COL_THREADS);
   switch (g.kp) {
     case 4:
-      hipLaunchKernelGGL((k_col_analysis<4>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2);
+      if (lift) hipLaunchKernelGGL((k_col_analysis<4, true>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
+      else hipLaunchKernelGGL((k_col_analysis<4, false>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
       hipLaunchKernelGGL((k_col_mix_synthesis<4>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
       break;
     case 8:
-      hipLaunchKernelGGL((k_col_analysis<8>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2);
+      if (lift) hipLaunchKernelGGL((k_col_analysis<8, true>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
+      else hipLaunchKernelGGL((k_col_analysis<8, false>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
       hipLaunchKernelGGL((k_col_mix_synthesis<8>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
       break;
     case 12:
-      hipLaunchKernelGGL((k_col_analysis<12>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2);
+      if (lift) hipLaunchKernelGGL((k_col_analysis<12, true>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
+      else hipLaunchKernelGGL((k_col_analysis<12, false>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
       hipLaunchKernelGGL((k_col_mix_synthesis<12>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
       break;
     default:
-      hipLaunchKernelGGL((k_col_analysis<16>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2);
+      if (lift) hipLaunchKernelGGL((k_col_analysis<16, true>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
+      else hipLaunchKernelGGL((k_col_analysis<16, false>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
       hipLaunchKernelGGL((k_col_mix_synthesis<16>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
       break;
   }
@@ -577,6 +615,50 @@ int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, c
   if (conv_syn_h2_ok(x, out, t1, Cin, Cout, M, N, 2 * kp))
     return conv_syn_h2(x, wc, bc, t1, pn->fs_t, out, B, Cin, Cout, M, N, 2 * kp, act_out, st);
   return conv1x1_syn(x, wc, bc, t1, pn->fs_t, out, B, Cin, Cout, M, N, 2 * kp, act_out, st);
+}
+
+// ---- evaluation-mode FNO2d: lifting + first block without the lifted field (reference models/fno.py:121-147:
+// cat(x, gridx, gridy) -> lifting -> fno_blocks[0]); u [B,1,M,N], gx [M], gy [N], wl [C,3], bl [C] ----
+size_t rpde_fno2d_lift_block_eval_ws_bytes(int B, int C, int Cout, int M, int N, int m1, int m2) {
+  const size_t kp = (size_t)((m2 + 3) / 4 * 4), R = 2 * (size_t)m1;
+  return arena_bytes((size_t)B * M * 2 * kp) + arena_bytes(4 * kp) + arena_bytes(2 * (size_t)N) +
+         arena_bytes((size_t)B * C * 2 * R * kp) + arena_bytes((size_t)B * Cout * M * 2 * kp) + 4096;
+}
+
+int rpde_fno2d_lift_block_eval_ok(int Cu, int C, int Cout, int M, int N, int m1, int m2) {
+  if (const char* e = getenv("RPDE_LIFT_FUSED")) if (e[0] == '0') return 0;
+  const int kp = (m2 + 3) / 4 * 4;
+  return Cu == 1 && M <= 1024 && m2 <= N / 2 + 1 && m1 <= M && conv_syn_h2_ok(nullptr, nullptr, nullptr, C, Cout, M, N, 2 * kp) &&
+         col_stage_ok(M, m1, kp, nullptr, nullptr) ? 1 : 0;
+}
+
+int rpde_fno2d_lift_block_eval_fwd(const float* u, const float* gx, const float* gy, const float* wl, const float* bl,
+                                   const float* w1, const float* w2, const float* wc, const float* bc, float* out, int B, int C,
+                                   int Cout, int M, int N, int m1, int m2, int act_out, void* ws, size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(u && gx && gy && wl && w1 && w2 && wc && out && B > 0 && C > 0 && Cout > 0 && M > 0 && N > 0 && m1 > 0 && m2 > 0,
+                 "fno2d_lift_block_eval_fwd: bad arguments");
+  RPDE_CHECK_ARG(rpde_fno2d_lift_block_eval_ok(1, C, Cout, M, N, m1, m2), "fno2d_lift_block_eval_fwd: shape not covered");
+  hipStream_t st = as_stream(stream);
+  const rpde_plan *pn, *pm;
+  RPDE_TRY(get_plan(&pn, N, m2, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));
+  RPDE_TRY(get_plan(&pm, M, m1, RPDE_NORM_BACKWARD, 0, PLAN_CPLX, st));
+  const int kp = pn->kp, R = 2 * m1;
+  Arena ar(ws, ws_bytes);
+  float* su = ar.take((size_t)B * M * 2 * kp);
+  float* sc = ar.take(4 * (size_t)kp);
+  float* rows2 = ar.take(2 * (size_t)N);
+  float* s2 = ar.take((size_t)B * C * 2 * R * kp);
+  float* t1 = ar.take((size_t)B * Cout * M * 2 * kp);
+  if (!ar.ok()) { set_error("fno2d_lift_block_eval_fwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  RPDE_CHECK_ARG(((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0,
+                 "fno2d_lift_block_eval_fwd: u, gy and out must be 16-byte aligned");
+  hipLaunchKernelGGL(k_lift_const_rows, dim3((N + 255) / 256), dim3(256), 0, st, gy, rows2, N);
+  RPDE_TRY(cf_analysis(pn, rows2, sc, 2, N, 0, st));
+  RPDE_TRY(cf_analysis(pn, u, su, (long)B * M, N, 0, st));
+  MixGeom g{B, C, Cout, R, m1, m2, kp};
+  ColLift L{su, sc, wl, bl, gx, C};
+  RPDE_TRY(col_stage(pm, nullptr, s2, w1, w2, t1, g, M, st, &L));
+  return conv_syn_h2(nullptr, wc, bc, t1, pn->fs_t, out, B, C, Cout, M, N, 2 * kp, act_out, st, u, wl, bl, gx, gy);
 }
 
 int rpde_spectral2d_bwd(const float* grad_out, const float* spec_in, const float* w1, const float* w2, const float* x,

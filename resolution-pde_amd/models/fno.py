@@ -75,7 +75,31 @@ class FNO2d(_FNO):
         gy = gy.reshape(1, 1, n, 1).repeat([b, m, 1, 1])
         return torch.cat((gx, gy), dim=-1)
 
+    def _grid_axes(self, m, n, device):
+        """the two coordinate vectors as device arrays (cached per shape: evaluation loops call this every step)"""
+        if self.grid is not None:
+            return _coord(self.grid[0], device), _coord(self.grid[1], device)
+        key = (m, n, str(device))
+        hit = getattr(self, "_axes_cache", None)
+        if hit is None or hit[0] != key:
+            gx = torch.tensor(np.linspace(0, 1, m), dtype=torch.float).to(device)
+            gy = torch.tensor(np.linspace(0, 1, n), dtype=torch.float).to(device)
+            self._axes_cache = hit = (key, gx, gy)
+        return hit[1], hit[2]
+
     def forward(self, x):
+        if not torch.is_grad_enabled() and len(self.fno_blocks) > 0 and x.dim() == 4 and x.shape[1] == 1 and x.is_cuda:
+            # evaluation / rollout: grid concat, lifting and the first block in one library call -- the lifted field
+            # (width x the input) is formed inside the kernels and never crosses HBM
+            blk = self.fno_blocks[0]
+            ax, ay = self._grid_axes(x.shape[2], x.shape[3], x.device)
+            h = ops.fno2d_lift_block_eval(x, ax, ay, self.lifting.weight, self.lifting.bias, blk.spectral_conv.weights1,
+                                          blk.spectral_conv.weights2, blk.bypass_conv.weight, blk.bypass_conv.bias,
+                                          act_name(blk.activation))
+            if h is not None:
+                for b in self.fno_blocks[1:]:
+                    h = b.activated(h)
+                return self.projection(h, "identity")
         gx = gy = None
         if self.grid is not None:
             gx, gy = _coord(self.grid[0], x.device), _coord(self.grid[1], x.device)

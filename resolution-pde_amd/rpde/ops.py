@@ -523,6 +523,32 @@ def fnoblock2d_eval(x, w1, w2, wc, bc, act_out: str):
     return out
 
 
+def fno2d_lift_block_eval(u, gx, gy, wl, bl, w1, w2, wc, bc, act_out: str):
+    """evaluation only (no autograd): act_out(SpectralConv2d(x0) + conv1x1(x0)) with x0 = lifting(cat(u, gx, gy)) formed on
+    the fly (rpde_fno2d_lift_block_eval_fwd: the lifted field is never written); u [B,1,M,N], gx [M], gy [N] device
+    arrays.  None when the shape is not covered."""
+    lib = load()
+    if u.dim() != 4 or u.shape[1] != 1 or not u.is_cuda:
+        return None
+    B, _, M, N = u.shape
+    C, Co, m1, m2 = w1.shape[0], w1.shape[1], w1.shape[2], w1.shape[3]
+    if wl.shape[0] != C or wl[0].numel() != 3 or not lib.rpde_fno2d_lift_block_eval_ok(1, C, Co, M, N, m1, m2):
+        return None
+    u = _f32c(u)
+    gx, gy = _f32c(gx), _f32c(gy)
+    wlf = _f32c(wl.detach()).reshape(C, 3)
+    blf = _f32c(bl.detach()) if bl is not None else None
+    wcf = _f32c(wc.detach()).reshape(Co, C)
+    bcf = _f32c(bc.detach()) if bc is not None else None
+    out = torch.empty(B, Co, M, N, dtype=torch.float32, device=u.device)
+    nws = lib.rpde_fno2d_lift_block_eval_ws_bytes(B, C, Co, M, N, m1, m2)
+    ws = workspace(nws, u.device)
+    check(lib.rpde_fno2d_lift_block_eval_fwd(ptr(u), ptr(gx), ptr(gy), ptr(wlf), ptr(blf), ptr(_as_float_storage(w1.detach())),
+                                             ptr(_as_float_storage(w2.detach())), ptr(wcf), ptr(bcf), ptr(out), B, C, Co, M, N,
+                                             m1, m2, ACT[act_out], ws.data_ptr(), nws, stream_ptr()), "fno2d_lift_block_eval_fwd")
+    return out
+
+
 def conv_mlp_eval(x, w1, b1, w2, b2, act_in: str = "identity"):
     """evaluation only (no autograd): mlp2(gelu(mlp1(act_in(x)))) of the FNO projection in one pass, or None when the
     shape is not covered (the caller then runs the two convolutions)"""

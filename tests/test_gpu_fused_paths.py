@@ -194,6 +194,45 @@ def test_fno2d_evaluation_path_equals_training_path_forward(gpu_device):
     assert _rel(e1, m1(x1.requires_grad_(True)).detach()) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 128, 6, 6), (1, 512, 512, 12, 12), (3, 40, 256, 5, 9), (2, 77, 64, 3, 4)])
+@pytest.mark.parametrize("user_grid", [False, True])
+def test_fno2d_lifted_first_block_equals_the_unfused_path(gpu_device, shape, user_grid):
+    """rpde_fno2d_lift_block_eval_fwd (grid concat + lifting + first FNO block without the lifted field: row spectra by
+    linearity in k_col_analysis<.., LIFT>, the slab formed on the fly in k_conv_syn_h2<.., LIFT>) against the model with
+    RPDE_LIFT_FUSED=0 (concat kernel, lifting convolution, fnoblock2d_eval) and against the training-mode forward"""
+    import numpy as np
+    from models.fno import FNO2d
+    from rpde import _lib
+    B, M, N, m1, m2 = shape
+    torch.manual_seed(M + N)
+    grid = None
+    if user_grid:
+        grid = (np.sort(np.random.RandomState(1).rand(M)).astype(np.float32), np.linspace(-2.0, 3.0, N).astype(np.float32))
+    model = FNO2d(1, 1, modes1=m1, modes2=m2, width=32, grid=grid).to(gpu_device).eval()
+    x = torch.randn(B, 1, M, N, device=gpu_device) * torch.logspace(-2, 2, M, device=gpu_device).view(1, 1, M, 1)
+    assert _lib.load().rpde_fno2d_lift_block_eval_ok(1, 32, 32, M, N, m1, m2) == 1
+    with torch.no_grad():
+        fused = model(x)
+    old = os.environ.get("RPDE_LIFT_FUSED")
+    os.environ["RPDE_LIFT_FUSED"] = "0"
+    try:
+        with torch.no_grad():
+            plain = model(x)
+    finally:
+        if old is None:
+            os.environ.pop("RPDE_LIFT_FUSED")
+        else:
+            os.environ["RPDE_LIFT_FUSED"] = old
+    train = model(x.clone().requires_grad_(True)).detach()
+    assert torch.isfinite(fused).all()
+    # per row (the rows differ by four orders of magnitude)
+    num = (fused - plain).flatten(0, 1).norm(dim=-1)
+    den = plain.flatten(0, 1).norm(dim=-1).clamp_min(1e-30)
+    assert float((num / den).max()) < 1e-5, float((num / den).max())
+    assert _rel(fused, plain) < 2e-6, _rel(fused, plain)
+    assert _rel(fused, train) < 2e-6, _rel(fused, train)
+
+
 @pytest.mark.parametrize("in_f,out_f", [(256, 256), (64, 256), (256, 64)])
 @pytest.mark.parametrize("P", [32 * 640, 32 * 811 + 7])
 def test_streaming_weight_gradient_kernel(gpu_device, in_f, out_f, P):
