@@ -24,7 +24,8 @@ buf = (C.c_ulonglong * (2 * 64 * 32))()
 lib.rpde_debug_fused_stamps.argtypes = [C.c_void_p]
 _lib.check(lib.rpde_debug_fused_stamps(buf), "stamps")
 t = np.array(buf, dtype=np.uint64).reshape(2, 64, 32).astype(np.int64)
-for k, name in ((0, "analysis: per chunk [start, max done, split+LDS written, MFMA done]"), (1, "synthesis")):
+for k, name in ((0, "analysis_sq, units 9..11 of one wave: [top, y landed, y done, B1 passed, partials written, B2 passed, "
+                    "reduced+stored, B3 passed, x landed, x done] x 3"), (1, "synthesis")):
     a = t[k]
     a = a[a[:, 0] > 0]
     rel = a - a[:, :1]

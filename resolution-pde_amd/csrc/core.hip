@@ -225,6 +225,7 @@ int rpde_plan_destroy(rpde_plan* p) {
   for (int i = 0; i < 4; ++i) if (p->img[i]) (void)hipFree(p->img[i]);
   for (int i = 0; i < 2; ++i) {
     if (p->h2_ana[i]) (void)hipFree(p->h2_ana[i]);
+    if (p->h2_ana_p[i]) (void)hipFree(p->h2_ana_p[i]);
     if (p->h2_syn[i]) (void)hipFree(p->h2_syn[i]);
     if (p->cf_ana[i]) (void)hipFree(p->cf_ana[i]);
     if (p->cf_syn[i]) (void)hipFree(p->cf_syn[i]);

@@ -34,14 +34,19 @@ __device__ unsigned long long g_fstamps[2][64 * 32];
 // ------------------------------------------------------------------------------------------------------------
 // analysis operand of T[r][y] = src[r*rs + y*cs] (r < R, y < n): fragment (s, mt, piece) holds for lane l the
 // eight entries T[16 mt + (l & 15)][32 s + 8 (l >> 4) + j] * 2^12
+// perm: slot j of lane group g holds reduction index 32 s + 4 j + g instead of 32 s + 8 g + j (the points a lane of
+// k_dft_analysis_sq_h2 loads)
 __global__ __launch_bounds__(64) void k_h2_table_ana(const float* __restrict__ src, long rs, long cs, int R, int n, int MT,
-                                                     char* __restrict__ out) {
+                                                     char* __restrict__ out, int perm) {
   const int f = blockIdx.x, l = threadIdx.x;
   const int s = f / MT, mt = f % MT;
-  const int r = 16 * mt + (l & 15), y0 = 32 * s + 8 * (l >> 4);
+  const int r = 16 * mt + (l & 15), g = l >> 4;
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (r < R && y0 + j < n) ? src[r * rs + (y0 + j) * cs] * (float)(1 << H2_TABLE_EXP) : 0.f;
+  for (int j = 0; j < 8; ++j) {
+    const int y = 32 * s + (perm ? 4 * j + g : 8 * g + j);
+    v[j] = (r < R && y < n) ? src[r * rs + y * cs] * (float)(1 << H2_TABLE_EXP) : 0.f;
+  }
   uint2 h0, l0, h1, l1;
   h2_split4(v[0], v[1], v[2], v[3], h0, l0);
   h2_split4(v[4], v[5], v[6], v[7], h1, l1);
@@ -112,12 +117,15 @@ int h2_build_tables(rpde_plan* p, hipStream_t st) {
   const int MT = (R + 15) / 16, K32 = R / 32, TG = (R % 32) / 8;
   for (int i = 0; i < 2; ++i) {
     RPDE_HIP(hipMalloc(&p->h2_ana[i], h2_ana_bytes(n, R)));
+    RPDE_HIP(hipMalloc(&p->h2_ana_p[i], h2_ana_bytes(n, R)));
     RPDE_HIP(hipMalloc(&p->h2_syn[i], h2_syn_bytes(n, R)));
   }
   const dim3 ga((n / 32) * MT), gs((n + 15) / 16);
   // [0]: forward operands (Fa analysis, Fs synthesis); [1]: adjoint operands (Fs^T analysis, Fa^T synthesis)
-  hipLaunchKernelGGL(k_h2_table_ana, ga, dim3(64), 0, st, p->fa, (long)p->ldn, 1L, R, n, MT, (char*)p->h2_ana[0]);
-  hipLaunchKernelGGL(k_h2_table_ana, ga, dim3(64), 0, st, p->fs, 1L, (long)R, R, n, MT, (char*)p->h2_ana[1]);
+  hipLaunchKernelGGL(k_h2_table_ana, ga, dim3(64), 0, st, p->fa, (long)p->ldn, 1L, R, n, MT, (char*)p->h2_ana[0], 0);
+  hipLaunchKernelGGL(k_h2_table_ana, ga, dim3(64), 0, st, p->fs, 1L, (long)R, R, n, MT, (char*)p->h2_ana[1], 0);
+  hipLaunchKernelGGL(k_h2_table_ana, ga, dim3(64), 0, st, p->fa, (long)p->ldn, 1L, R, n, MT, (char*)p->h2_ana_p[0], 1);
+  hipLaunchKernelGGL(k_h2_table_ana, ga, dim3(64), 0, st, p->fs, 1L, (long)R, R, n, MT, (char*)p->h2_ana_p[1], 1);
   hipLaunchKernelGGL(k_h2_table_syn, gs, dim3(64), 0, st, p->fs, (long)R, 1L, n, R, K32, TG, (char*)p->h2_syn[0]);
   hipLaunchKernelGGL(k_h2_table_syn, gs, dim3(64), 0, st, p->fa, 1L, (long)p->ldn, n, R, K32, TG, (char*)p->h2_syn[1]);
   RPDE_LAUNCH_CHECK();
@@ -411,12 +419,23 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
 #pragma unroll
     for (int i = 0; i < 8; ++i) buf[i] = gload(q0 + i * 256);
   };
-  // the chunk in buf has landed once at most `younger` later vector-memory instructions are outstanding
-  auto landed = [&](f32x4v (&buf)[8], bool other_duty) {
-    if (other_duty)
-      asm volatile("s_waitcnt vmcnt(8)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])::"memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])::"memory");
+  // The chunk in buf has landed once at most N later vector-memory instructions are outstanding.  N counts what is
+  // CERTAIN to have been issued behind it: the other axis's 8 loads and this wave's spectrum stores of the reduction in
+  // between (`nst`, wave-uniform: the items of the reduction loop whose first lane group has a valid row, plus the line
+  // maximum written by wave 0) -- with the stores counted in, a wave no longer waits for their acknowledgement before
+  // it may touch data that arrived long ago (1.2-1.7 K of 13 K cycles per step).
+  int nst_wave = 0;
+  for (int e = 64 * wave; e < MT * 4 * 64; e += 64 * ANA_WAVES) nst_wave += (16 * (e >> 8) + ((e >> 6) & 3)) < P.R ? 1 : 0;
+  if (wave == 0 && P.amax_y) ++nst_wave;
+  auto landed = [&](f32x4v (&buf)[8], bool other_duty, bool stores_behind) {
+    const int nst = stores_behind ? nst_wave : 0;        // (the very first chunk has only the other axis's loads behind it)
+#define RPDE_LANDED(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])::"memory")
+    if (!other_duty) { RPDE_LANDED(0); }
+    else if (nst <= 0) { RPDE_LANDED(8); }
+    else if (nst == 1) { RPDE_LANDED(9); }
+    else if (nst == 2) { RPDE_LANDED(10); }
+    else { RPDE_LANDED(11); }
+#undef RPDE_LANDED
   };
   // one 32-point chunk into accumulators that stay in scaled units for the whole line (k_dft_analysis_h2's scheme)
   auto process = [&](f32x4v (&buf)[8], int s, f32x4v (&tot)[MT][4], int& line_E) {
@@ -440,35 +459,25 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
         line_E = E;
       }
     }
+    // No staging: the eight points a lane loaded for channel 4 li + e (buf[0..7], component e) ARE the eight reduction
+    // slots of its lane group in a B fragment whose column li stands for channel 4 li + e -- the table image carries the
+    // matching permutation of the reduction index (h2_ana_p).  Four fragments (e = 0..3) instead of four channel tiles;
+    // accumulator column li of tot[mt][e] is channel 4 li + e.
     const float scale = __uint_as_float((unsigned)(268 - line_E) << 23);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      uint2 hi, lo;
-      h2_split4(buf[i].x * scale, buf[i].y * scale, buf[i].z * scale, buf[i].w * scale, hi, lo);
-      const int off = stage_off(4 * i + g, li);
-      *reinterpret_cast<uint2*>(stage + off) = hi;
-      *reinterpret_cast<uint2*>(stage + 4096 + off) = lo;
-    }
-  };
-  auto mfma_chunk = [&](int s, f32x4v (&tot)[MT][4]) {
-    wave_lds_fence();
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const char* t = stage + trow + ((nt ^ tsw) << 5);
-      union { struct { s16x4v a, b; } h; f16x8 v; } bh, bl;
-      bh.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t));
-      bh.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 512));
-      bl.h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 4096));
-      bl.h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(t + 4096 + 512));
+    for (int e = 0; e < 4; ++e) {
+      union { f16x8 v; struct { uint2 a, b; } u; } H, L;
+      h2_split4(buf[0][e] * scale, buf[1][e] * scale, buf[2][e] * scale, buf[3][e] * scale, H.u.a, L.u.a);
+      h2_split4(buf[4][e] * scale, buf[5][e] * scale, buf[6][e] * scale, buf[7][e] * scale, H.u.b, L.u.b);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const char* ta = smem + (s * MT + mt) * 2048 + l * 16;
         const f16x8 ah = *reinterpret_cast<const f16x8*>(ta), al = *reinterpret_cast<const f16x8*>(ta + 1024);
-        tot[mt][nt] = h2_mfma32(ah, al, bh.v, bl.v, tot[mt][nt]);
+        tot[mt][e] = h2_mfma32(ah, al, H.v, L.v, tot[mt][e]);
       }
     }
-    wave_lds_fence();
   };
+  auto mfma_chunk = [&](int, f32x4v (&)[MT][4]) {};
 
   f32x4v totx[MT][4], toty[MT][4];
   int Ex = 0;
@@ -478,9 +487,19 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the table copy above: from here on the queue is counted by hand)
   issue_y(by, 0);
   issue_x(bx, 0);
+#ifdef RPDE_STAMPS
+  const bool stamp_wave = l == 0 && wave == 3 && blockIdx.x >= 96 && blockIdx.x < 160;
+  const int stamp_slot = (int)blockIdx.x - 96;
+#endif
   for (long u = 0; u < units; ++u) {
     const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
     const int b = xg + P.ng * sb;
+#ifdef RPDE_STAMPS
+    // units 9, 10, 11 (second sample, mid-line): 10 stamps each
+    const bool stamp_on = stamp_wave && u >= 9 && u < 12;
+    const int sq0 = (int)(u - 9) * 10;
+#endif
+    FSTAMP(0, sq0 + 0);
     // (y first: its loads -- whole rows, 64 KB contiguous per workgroup, 2 MB per group -- are then the ones that go
     //  to HBM, and the x axis's 256-byte pieces, requested a phase later, find the rows in the L2)
     // ---- y axis: row 32 t + jw of the block; this wave's chunk of it, then the sum over the chunks ----
@@ -491,7 +510,8 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) toty[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
       int Ey = 0;
-      landed(by, has_x);
+      landed(by, has_x, u > 0);
+      FSTAMP(0, sq0 + 1);
       process(by, wave, toty, Ey);
       issue_y(by, u + 1);
       mfma_chunk(wave, toty);
@@ -503,35 +523,46 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
     // staging areas + the reduction area together take all partials at once ([wave][mt][nt][lane] float4, 4 MT KB per
     // wave), one pass, two barriers
     char* const land = smem + TAB;                  // STG + RED = 112 KB >= 8 waves x 12 KB
+    FSTAMP(0, sq0 + 2);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everyone's chunks are out of the staging areas
+    FSTAMP(0, sq0 + 3);
+    // a lane's four fragments e = 0..3 hold channels 4 li .. 4 li + 3 of its rows: the partials land as
+    // [wave][mt][j][lane] float4 over those four channels, so the sum over the waves is a float4 per (row, li) and the
+    // spectrum leaves in 16-byte pieces, 256 contiguous bytes per 16 lanes (4-byte scattered stores made this phase the
+    // longest of a step: 3-3.8 K of 13.5 K cycles)
     if (has_y) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const f32x4v v = toty[mt][nt];
-          *reinterpret_cast<float4*>(land + ((wave * MT + mt) * 4 + nt) * 1024 + l * 16) =
-              make_float4(v[0] * invy, v[1] * invy, v[2] * invy, v[3] * invy);
-        }
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(land + ((wave * MT + mt) * 4 + j) * 1024 + l * 16) =
+              make_float4(toty[mt][0][j] * invy, toty[mt][1][j] * invy, toty[mt][2][j] * invy, toty[mt][3][j] * invy);
     }
+    FSTAMP(0, sq0 + 4);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    FSTAMP(0, sq0 + 5);
     float am = 0.f;
     for (int e = tid; e < MT * 4 * 64; e += 64 * ANA_WAVES) {
-      const int mt = e >> 8, nt = (e >> 6) & 3, ln = e & 63;
+      const int mt = e >> 8, j = (e >> 6) & 3, ln = e & 63;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int w2 = 0; w2 < steps; ++w2) {
-        const float4 v = *reinterpret_cast<const float4*>(land + ((w2 * MT + mt) * 4 + nt) * 1024 + ln * 16);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-      }
-      const int row0 = 16 * mt + 4 * (ln >> 4), ch = 16 * nt + (ln & 15);
-      const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (row0 + j < P.R) { spy[(row0 + j) * 64 + ch] = av[j]; am = fmaxf(am, fabsf(av[j])); }
+      for (int w2 = 0; w2 < ANA_WAVES; ++w2) {             // (all eight reads in flight; waves without a chunk wrote nothing)
+        if (w2 < steps) {
+          const float4 v = *reinterpret_cast<const float4*>(land + ((w2 * MT + mt) * 4 + j) * 1024 + ln * 16);
+          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+      }
+      const int row = 16 * mt + 4 * (ln >> 4) + j;
+      if (row < P.R) {
+        *reinterpret_cast<float4*>(spy + row * 64 + 4 * (ln & 15)) = a;
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+      }
     }
     am = wave_max(am);
     if (l == 0) wmax[wave] = am;                                           // (its own 32 bytes behind the landing zone)
+    FSTAMP(0, sq0 + 6);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the landing zone has been read: staging may be reused
+    FSTAMP(0, sq0 + 7);
     if (tid == 0 && P.amax_y) {
       float a8 = 0.f;
       for (int i = 0; i < ANA_WAVES; ++i) a8 = fmaxf(a8, wmax[i]);
@@ -546,7 +577,8 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
           for (int nt = 0; nt < 4; ++nt) totx[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         Ex = 0;
       }
-      landed(bx, has_y);
+      landed(bx, has_y, true);
+      FSTAMP(0, sq0 + 8);
       process(bx, t, totx, Ex);
       issue_x(bx, u + 1);
       mfma_chunk(t, totx);
@@ -560,10 +592,9 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int row = 16 * mt + 4 * g + j;
-            if (row < P.R) {
-#pragma unroll
-              for (int nt = 0; nt < 4; ++nt) sp[row * 64 + 16 * nt + li] = totx[mt][nt][j] * inv;
-            }
+            if (row < P.R)
+              *reinterpret_cast<float4*>(sp + row * 64 + 4 * li) =
+                  make_float4(totx[mt][0][j] * inv, totx[mt][1][j] * inv, totx[mt][2][j] * inv, totx[mt][3][j] * inv);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) am = fmaxf(am, fabsf(totx[mt][nt][j]));
           }
@@ -571,6 +602,7 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
         if (l == 0 && P.amax_x) P.amax_x[z] = am * inv;
       }
     }
+    FSTAMP(0, sq0 + 9);
   }
 }
 
@@ -1178,7 +1210,7 @@ int fused2d_analysis(const float* x, float* spec_y, float* spec_x, float* amax_y
     RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (ana_sq_ok(M, N, cus) && py->h2_ana[adjoint] == px->h2_ana[adjoint]) {
       AnaSqP Q;
-      Q.x = x; Q.timg = (const char*)py->h2_ana[adjoint]; Q.spec_y = spec_y; Q.spec_x = spec_x; Q.amax_y = amax_y; Q.amax_x = amax_x;
+      Q.x = x; Q.timg = (const char*)py->h2_ana_p[adjoint]; Q.spec_y = spec_y; Q.spec_x = spec_x; Q.amax_y = amax_y; Q.amax_x = amax_x;
       Q.B = B; Q.n = N; Q.ks = N / 32; Q.R = 2 * py->kp; Q.ng = B < 8 ? B : 8;
       const dim3 grid(32 * Q.ng), blk(64 * ANA_WAVES);
       const int MTq = (Q.R + 15) / 16;

@@ -19,6 +19,8 @@ struct rpde_plan {
   // real, interleaved plans with n % 32 == 0, n <= 256 and <= 24 padded modes: the tables as ready f16 hi/lo MFMA
   // fragments for the fused kernels (fused_spectral.hip): [0] forward operand (Fa / Fs), [1] adjoint (Fs^T / Fa^T)
   void* h2_ana[2];
+  void* h2_ana_p[2];   // the same with the reduction index permuted inside each 32-chunk (slot 8 g + j <-> point 4 j + g):
+                       // k_dft_analysis_sq_h2 builds its B fragments straight from the loaded registers
   void* h2_syn[2];
   // real, planar plans (channels-first layers, resizers) that cf_dft.hip covers: the tables as B fragments
   void* cf_ana[2];
