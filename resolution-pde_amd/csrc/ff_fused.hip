@@ -342,8 +342,13 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
         const int hid = 16 * (2 * w + t) + 4 * g;
         ff_act4(acc, inv1, *reinterpret_cast<const float4*>(vec + hid), A.drop[0], (uint64_t)(pt * 256 + hid), h, d, u);
         if (MODE == 1 && pt < A.P) {
+#ifdef RPDE_EXP_CONTIG      // timing experiment: each store instruction writes 1 KB contiguous (fragment-major saved tensors)
+          *reinterpret_cast<float4*>(A.h1 + p0 * 256 + ((blk * 8 + w) * 2 + t) * 256 + l * 4) = make_float4(h[0], h[1], h[2], h[3]);
+          *reinterpret_cast<float4*>(A.d1 + p0 * 256 + ((blk * 8 + w) * 2 + t) * 256 + l * 4) = make_float4(d[0], d[1], d[2], d[3]);
+#else
           *reinterpret_cast<float4*>(A.h1 + pt * 256 + hid) = make_float4(h[0], h[1], h[2], h[3]);
           *reinterpret_cast<float4*>(A.d1 + pt * 256 + hid) = make_float4(d[0], d[1], d[2], d[3]);
+#endif
         }
         if (MODE == 2 && pt < A.P) *reinterpret_cast<float4*>(A.h1 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
 #pragma unroll
@@ -383,8 +388,13 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
         ff_act4(acc[t], inv2, *reinterpret_cast<const float4*>(vec + 256 + hid), A.drop[1], (uint64_t)(pt * 256 + hid), h, d, u);
         if (MODE == 2 && pt < A.P) *reinterpret_cast<float4*>(A.h2 + pt * 256 + hid) = make_float4(u[0], u[1], u[2], u[3]);
         if (MODE == 1 && pt < A.P) {
+#ifdef RPDE_EXP_CONTIG
+          *reinterpret_cast<float4*>(A.h2 + p0 * 256 + ((blk * 8 + w) * 2 + t) * 256 + l * 4) = make_float4(h[0], h[1], h[2], h[3]);
+          *reinterpret_cast<float4*>(A.d2 + p0 * 256 + ((blk * 8 + w) * 2 + t) * 256 + l * 4) = make_float4(d[0], d[1], d[2], d[3]);
+#else
           *reinterpret_cast<float4*>(A.h2 + pt * 256 + hid) = make_float4(h[0], h[1], h[2], h[3]);
           *reinterpret_cast<float4*>(A.d2 + pt * 256 + hid) = make_float4(d[0], d[1], d[2], d[3]);
+#endif
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[4 * t + r] = h[r] * sh2;
