@@ -485,8 +485,8 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
 #pragma unroll
   for (int i = 0; i < 8; ++i) bx[i] = by[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the table copy above: from here on the queue is counted by hand)
-  issue_y(by, 0);
   issue_x(bx, 0);
+  issue_y(by, 0);
 #ifdef RPDE_STAMPS
   const bool stamp_wave = l == 0 && wave == 3 && blockIdx.x >= 96 && blockIdx.x < 160;
   const int stamp_slot = (int)blockIdx.x - 96;
@@ -500,8 +500,42 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
     const int sq0 = (int)(u - 9) * 10;
 #endif
     FSTAMP(0, sq0 + 0);
-    // (y first: its loads -- whole rows, 64 KB contiguous per workgroup, 2 MB per group -- are then the ones that go
-    //  to HBM, and the x axis's 256-byte pieces, requested a phase later, find the rows in the L2)
+    // (x first.  The other order -- whole 64 KB rows going to HBM, the x axis's 256-byte pieces finding them in L2 -- was
+    //  measured: same time, but 604 instead of 553 MB fetched per launch)
+    // ---- x axis: this wave's column, rows of block t ----
+    if (has_x) {
+      if (t == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) totx[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        Ex = 0;
+      }
+      landed(bx, has_y, u > 0);
+      FSTAMP(0, sq0 + 8);
+      process(bx, t, totx, Ex);
+      issue_x(bx, u + 1);
+      mfma_chunk(t, totx);
+      if (t == steps - 1) {
+        const long z = (long)b * n + gw;
+        float* __restrict__ sp = P.spec_x + z * (long)P.R * 64;
+        const float inv = __uint_as_float((unsigned)(Ex - 14 - H2_TABLE_EXP) << 23);
+        float am = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = 16 * mt + 4 * g + j;
+            if (row < P.R)
+              *reinterpret_cast<float4*>(sp + row * 64 + 4 * li) =
+                  make_float4(totx[mt][0][j] * inv, totx[mt][1][j] * inv, totx[mt][2][j] * inv, totx[mt][3][j] * inv);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) am = fmaxf(am, fabsf(totx[mt][nt][j]));
+          }
+        am = wave_max(am);
+        if (l == 0 && P.amax_x) P.amax_x[z] = am * inv;
+      }
+    }
     // ---- y axis: row 32 t + jw of the block; this wave's chunk of it, then the sum over the chunks ----
     float invy = 0.f;
     if (has_y) {
@@ -567,40 +601,6 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
       float a8 = 0.f;
       for (int i = 0; i < ANA_WAVES; ++i) a8 = fmaxf(a8, wmax[i]);
       P.amax_y[zy] = a8;
-    }
-    // ---- x axis: this wave's column, rows of block t ----
-    if (has_x) {
-      if (t == 0) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) totx[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-        Ex = 0;
-      }
-      landed(bx, has_y, true);
-      FSTAMP(0, sq0 + 8);
-      process(bx, t, totx, Ex);
-      issue_x(bx, u + 1);
-      mfma_chunk(t, totx);
-      if (t == steps - 1) {
-        const long z = (long)b * n + gw;
-        float* __restrict__ sp = P.spec_x + z * (long)P.R * 64;
-        const float inv = __uint_as_float((unsigned)(Ex - 14 - H2_TABLE_EXP) << 23);
-        float am = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int row = 16 * mt + 4 * g + j;
-            if (row < P.R)
-              *reinterpret_cast<float4*>(sp + row * 64 + 4 * li) =
-                  make_float4(totx[mt][0][j] * inv, totx[mt][1][j] * inv, totx[mt][2][j] * inv, totx[mt][3][j] * inv);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) am = fmaxf(am, fabsf(totx[mt][nt][j]));
-          }
-        am = wave_max(am);
-        if (l == 0 && P.amax_x) P.amax_x[z] = am * inv;
-      }
     }
     FSTAMP(0, sq0 + 9);
   }
