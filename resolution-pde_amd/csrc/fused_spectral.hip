@@ -905,9 +905,8 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
   typedef const __attribute__((address_space(1))) void* glb_ptr;
 
   // ---- this workgroup's tiles.  Blocks b, b + 8, .. share an XCD (an L2): group x = blockIdx & 7 takes the samples
-  // x, x + 8, .., tile by tile, the four channel blocks of a tile next to each other (their 64-byte pieces complete each
-  // other's 256-byte lines in L2); its workgroups take the tiles round-robin, so the ~32 in flight are neighbours that
-  // share spectrum lines.  (Placement is a speed matter only.)
+  // x, x + 8, ..; its workgroups take the items round-robin, so the ~32 in flight are neighbours that share spectrum
+  // lines.  (Placement is a speed matter only.)
   const int tn = P.N >> 6, wps = (P.M >> 6) * tn * 4;
   const int ng = P.sy;            // groups: 8, or the batch size when that is smaller
   const int xg = blockIdx.x % ng, jw = blockIdx.x / ng, nj = gridDim.x / ng;
@@ -916,7 +915,13 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
   auto item_at = [&](long q) {
     Syn3Item it;
     const int sb = (int)(q / wps), t = (int)(q - (long)sb * wps);
-    const int b = xg + ng * sb, cb = t & 3, tile = t >> 2;
+    // channel blocks in pairs: first every tile of the sample for blocks 0 and 1, then for 2 and 3.  The ~32 workgroups
+    // of a group then work on ONE pair at a time -- the pair's fragments of a 256^2 sample (3.2 MB) stay in the 4 MB L2
+    // while all sixteen tiles use them (with the four blocks of a tile side by side only half of a sample's tiles ran
+    // together and the other half fetched the lines again: 319 MB for 201 MB of operands) -- and the two blocks of a
+    // pair still complete each other's 128-byte lines in L2.
+    const int half = wps >> 1, hb = t / half, r = t - hb * half;
+    const int b = xg + ng * sb, cb = 2 * hb + (r & 1), tile = r >> 1;
     const int m0 = (tile / tn) << 6, n0 = (tile % tn) << 6;
     it.gx = P.imgx + ((long)b * P.N + n0) * LB + cb * BB;
     it.gy = P.imgy + ((long)b * P.M + m0) * LB + cb * BB;
