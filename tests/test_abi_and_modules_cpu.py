@@ -97,3 +97,23 @@ def test_product_tree_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(dp, f)
+
+
+def test_every_environment_switch_is_documented():
+    """every RPDE_* variable the library or the host code reads appears in INTEGRATION.md"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for base, pat in (("resolution-pde_amd/csrc", r'getenv\("(RPDE_[A-Z0-9_]+)"\)'),
+                      ("resolution-pde_amd", r'environ(?:\.get)?[\(\[]"(RPDE_[A-Z0-9_]+)"'), (".", None)):
+        if pat is None:
+            files, pat = [os.path.join(root, "bench.py")], r'environ(?:\.get)?[\(\[]"(RPDE_[A-Z0-9_]+)"'
+        else:
+            files = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(root, base)) for f in fs
+                     if f.endswith((".hip", ".h", ".py"))]
+        for f in files:
+            with open(f, errors="ignore") as fh:
+                names.update(re.findall(pat, fh.read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc and not any(n.startswith(p[:-1]) and p in doc for p in ("RPDE_BENCH_*",)))
+    assert names and not missing, missing
