@@ -272,6 +272,8 @@ static int cf_rowdft(const float* table, long ld_table, bool transpose, int m_ou
 //                        its 2R table entries (contiguous) against the mixed block (LDS broadcasts), kp contiguous results.
 constexpr int COL_THREADS = 256;
 constexpr int COL_MIX_THREADS = 320;
+constexpr int COL_ANA_THREADS = 768;      // up to 12 waves: one group of four table rows each (2R <= 48), so that a
+                                          // workgroup's time is one sweep over the staged block, not three
 
 // LIFT (first block of an FNO2d in evaluation, rpde_fno2d_lift_block_eval_fwd): the block's input is the lifting
 // convolution of a one-channel field u and the grid coordinates, x0[c] = wl[c][0] u + wl[c][1] gx[m] + wl[c][2] gy[n] + bl[c].
@@ -289,17 +291,17 @@ struct ColLift {
 };
 
 template <int KP, bool LIFT>
-__global__ __launch_bounds__(COL_THREADS) void k_col_analysis(const float* __restrict__ fa, const float* __restrict__ s1,
+__global__ __launch_bounds__(COL_ANA_THREADS) void k_col_analysis(const float* __restrict__ fa, const float* __restrict__ s1,
                                                               float* __restrict__ s2, int M2, int R2, ColLift L) {
   extern __shared__ __attribute__((aligned(16))) float col_sm[];
-  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, nth = blockDim.x;
   const long bc = blockIdx.x;
   if (LIFT) {
     const int b = (int)(bc / L.C), c = (int)(bc % L.C);
     const float wu = L.wl[c * 3], wx = L.wl[c * 3 + 1], wy = L.wl[c * 3 + 2], bb = L.bl ? L.bl[c] : 0.f;
     const float4* src = reinterpret_cast<const float4*>(L.su + (long)b * M2 * KP);      // [M][2 KP] = [2M][KP]
     float4* dst = reinterpret_cast<float4*>(col_sm);
-    for (int e = tid; e < M2 * KP / 4; e += COL_THREADS) {
+    for (int e = tid; e < M2 * KP / 4; e += nth) {
       const int mu = (4 * e) / KP, col = (mu & 1) * KP + (4 * e) % KP;     // (KP % 4 == 0: a float4 stays inside a row)
       const float4 one = *reinterpret_cast<const float4*>(L.sc + col), gy = *reinterpret_cast<const float4*>(L.sc + 2 * KP + col);
       const float a = fmaf(wx, L.gx[mu >> 1], bb);
@@ -310,12 +312,12 @@ __global__ __launch_bounds__(COL_THREADS) void k_col_analysis(const float* __res
   } else {
     const float4* src = reinterpret_cast<const float4*>(s1 + bc * (long)M2 * KP);
     float4* dst = reinterpret_cast<float4*>(col_sm);
-    for (int e = tid; e < M2 * KP / 4; e += COL_THREADS) dst[e] = src[e];
+    for (int e = tid; e < M2 * KP / 4; e += nth) dst[e] = src[e];
   }
   __syncthreads();
   // four table rows at a time: a row of the staged block (kp values from LDS) then feeds 4 kp multiply-adds -- with one
   // row at a time the kernel was bound by the LDS return path (79 us)
-  for (int rho0 = 4 * wv; rho0 < R2; rho0 += 4 * (COL_THREADS / 64)) {
+  for (int rho0 = 4 * wv; rho0 < R2; rho0 += 4 * (nth >> 6)) {
     float acc[4][KP];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -450,25 +452,27 @@ static int col_stage(const rpde_plan* pm, const float* s1, float* s2, const floa
   const size_t lds_a = sizeof(float) * (size_t)M2 * g.kp, lds_b = sizeof(float) * (size_t)R2 * g.kp;
   const dim3 ga((unsigned)(g.B * g.Ci)), gb((unsigned)(g.B * g.Co)), bk(COL_THREADS);
   const dim3 bkm(g.R * g.kp > COL_THREADS ? COL_MIX_THREADS : COL_THREADS);
+  const int wa = (R2 / 4 + 0) < 4 ? 4 : (R2 / 4 > COL_ANA_THREADS / 64 ? COL_ANA_THREADS / 64 : R2 / 4);
+  const dim3 bka(64 * wa);
   switch (g.kp) {
     case 4:
-      if (lift) hipLaunchKernelGGL((k_col_analysis<4, true>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
-      else hipLaunchKernelGGL((k_col_analysis<4, false>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
+      if (lift) hipLaunchKernelGGL((k_col_analysis<4, true>), ga, bka, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
+      else hipLaunchKernelGGL((k_col_analysis<4, false>), ga, bka, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
       hipLaunchKernelGGL((k_col_mix_synthesis<4>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
       break;
     case 8:
-      if (lift) hipLaunchKernelGGL((k_col_analysis<8, true>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
-      else hipLaunchKernelGGL((k_col_analysis<8, false>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
+      if (lift) hipLaunchKernelGGL((k_col_analysis<8, true>), ga, bka, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
+      else hipLaunchKernelGGL((k_col_analysis<8, false>), ga, bka, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
       hipLaunchKernelGGL((k_col_mix_synthesis<8>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
       break;
     case 12:
-      if (lift) hipLaunchKernelGGL((k_col_analysis<12, true>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
-      else hipLaunchKernelGGL((k_col_analysis<12, false>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
+      if (lift) hipLaunchKernelGGL((k_col_analysis<12, true>), ga, bka, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
+      else hipLaunchKernelGGL((k_col_analysis<12, false>), ga, bka, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
       hipLaunchKernelGGL((k_col_mix_synthesis<12>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
       break;
     default:
-      if (lift) hipLaunchKernelGGL((k_col_analysis<16, true>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
-      else hipLaunchKernelGGL((k_col_analysis<16, false>), ga, bk, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
+      if (lift) hipLaunchKernelGGL((k_col_analysis<16, true>), ga, bka, lds_a, st, pm->fa, s1, s2, M2, R2, *lift);
+      else hipLaunchKernelGGL((k_col_analysis<16, false>), ga, bka, lds_a, st, pm->fa, s1, s2, M2, R2, ColLift{});
       hipLaunchKernelGGL((k_col_mix_synthesis<16>), gb, bkm, lds_b, st, s2, w1, w2, pm->fs_t, t1, g, M2);
       break;
   }
