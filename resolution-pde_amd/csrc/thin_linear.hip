@@ -112,7 +112,31 @@ __global__ __launch_bounds__(TL_THREADS) void k_thin_outer(const float* __restri
   float acc[T][4], cs[4] = {0.f, 0.f, 0.f, 0.f}, ts[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) { ts[t] = 0.f; acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f; }
-  for (long p = p0 + pl; p < p1; p += pps) {
+  // eight points per thread in flight (all loads first, then the multiply-adds in point order: the sums do not change).
+  // With one load per thread and iteration the kernel ran at 2 TB/s -- 16 KB in flight per CU.
+  constexpr int UN = 8;
+  long p = p0 + pl;
+  for (; p + (long)(UN - 1) * pps < p1; p += (long)UN * pps) {
+    float4 v[UN];
+    float at[UN][T];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      v[u] = *reinterpret_cast<const float4*>(b + (p + (long)u * pps) * O + 4 * og);
+#pragma unroll
+      for (int t = 0; t < T; ++t) at[u][t] = a[(p + (long)u * pps) * T + t];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      cs[0] += v[u].x; cs[1] += v[u].y; cs[2] += v[u].z; cs[3] += v[u].w;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        ts[t] += at[u][t];
+        acc[t][0] = fmaf(at[u][t], v[u].x, acc[t][0]); acc[t][1] = fmaf(at[u][t], v[u].y, acc[t][1]);
+        acc[t][2] = fmaf(at[u][t], v[u].z, acc[t][2]); acc[t][3] = fmaf(at[u][t], v[u].w, acc[t][3]);
+      }
+    }
+  }
+  for (; p < p1; p += pps) {
     const float4 v = *reinterpret_cast<const float4*>(b + p * O + 4 * og);
     cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w;
 #pragma unroll
