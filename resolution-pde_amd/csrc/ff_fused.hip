@@ -75,8 +75,8 @@ __global__ __launch_bounds__(1024) void k_ff3_prep(const float* __restrict__ w1,
 #pragma unroll
     for (int i = 0; i < 16; ++i) m2 = fmaxf(m2, fmaxf(fmaxf(fabsf(b[i].x), fabsf(b[i].y)), fmaxf(fabsf(b[i].z), fabsf(b[i].w))));
   }
-#pragma unroll 4
-  for (int row = wv; row < 256; row += 16) {          // row L1 norms, one wave per row (coalesced)
+#pragma unroll
+  for (int row = wv; row < 256; row += 16) {          // row L1 norms, one wave per row (coalesced); all 16 rows' loads in flight
     float a = fabsf(w1[row * 64 + l]);
     float b = (fabsf(w2[row * 256 + l]) + fabsf(w2[row * 256 + 64 + l])) + (fabsf(w2[row * 256 + 128 + l]) + fabsf(w2[row * 256 + 192 + l]));
     r1 = fmaxf(r1, wave_sum_dpp(a));
@@ -522,8 +522,12 @@ __global__ __launch_bounds__(1024) void k_ff3_prep_bwd(const float* __restrict__
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int f = 0; f < 16; ++f) a += fabsf(w3[(16 * part + f) * 256 + col]);
-#pragma unroll 16
-    for (int k = 0; k < 64; ++k) b += fabsf(w2[(64 * part + k) * 256 + col]);
+    // (all 64 loads of a thread in flight at once: this launch sits in front of every backward)
+    float wv2[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wv2[k] = w2[(64 * part + k) * 256 + col];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) b += fabsf(wv2[k]);
     colp[0][part][col] = a; colp[1][part][col] = b;
     __syncthreads();
     if (tid < 256) {
