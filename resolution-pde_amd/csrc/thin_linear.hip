@@ -78,39 +78,27 @@ __global__ __launch_bounds__(TL_THREADS) void k_thin_contract(const float* __res
 #pragma unroll
   for (int t = 0; t < T; ++t) br[t] = bias ? bias[t] : 0.f;
   const long sweeps = (P + 15) / 16;
-  // four sweeps per pass, their loads issued together (one 16-byte load in flight per thread left the kernel at 4.2 TB/s);
-  // whole rows of 16 lanes stay together: DPP sums
-  constexpr int UN = 4;
-  for (long sw0 = blockIdx.x; sw0 < sweeps; sw0 += (long)UN * gridDim.x) {
-    float4 v[UN][NQ];
+  // (four sweeps per pass with their loads issued together was measured slower: 138 vs 126 us)
+  for (long sw = blockIdx.x; sw < sweeps; sw += gridDim.x) {        // whole rows of 16 lanes stay together: DPP sums
+    const long p = sw * 16 + pl;
+    const bool live = p < P;
+    float s[T];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const long p = (sw0 + (long)u * gridDim.x) * 16 + pl;
+    for (int t = 0; t < T; ++t) s[t] = 0.f;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int o = 64 * q + 4 * li;
-        v[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < P && o < O) v[u][q] = *reinterpret_cast<const float4*>(a + p * O + o);
-      }
+    for (int q = 0; q < NQ; ++q) {
+      const int o = 64 * q + 4 * li;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && o < O) v = *reinterpret_cast<const float4*>(a + p * O + o);
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        s[t] += (v.x * wr[t][q][0] + v.y * wr[t][q][1]) + (v.z * wr[t][q][2] + v.w * wr[t][q][3]);
     }
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const long p = (sw0 + (long)u * gridDim.x) * 16 + pl;
-      const bool live = p < P;
-      float s[T];
+    for (int t = 0; t < T; ++t) s[t] = tl_row_sum15(s[t]);
+    if (live && li == 15) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) s[t] = 0.f;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-          s[t] += (v[u][q].x * wr[t][q][0] + v[u][q].y * wr[t][q][1]) + (v[u][q].z * wr[t][q][2] + v[u][q].w * wr[t][q][3]);
-#pragma unroll
-      for (int t = 0; t < T; ++t) s[t] = tl_row_sum15(s[t]);
-      if (live && li == 15) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) y[p * T + t] = s[t] + br[t];
-      }
+      for (int t = 0; t < T; ++t) y[p * T + t] = s[t] + br[t];
     }
   }
 }
