@@ -23,6 +23,17 @@ from dataloaders.ns_naive_markov import NormalizedDataset, SimpleNormalizer
 from utils.low_pass_filter import lowpass_filter_1d
 
 
+def _resolve(saved_folder: str, filename: str) -> str:
+    """<saved_folder>/<filename>, or the .npz archive of the same stem when that file is absent (the default validation /
+    test names end in .h5; a tree of .npz archives -- the build image has no h5py -- then works with the defaults)"""
+    path = os.path.join(os.path.abspath(saved_folder), filename)
+    if not os.path.exists(path):
+        alt = os.path.splitext(path)[0] + ".npz"
+        if os.path.exists(alt):
+            return alt
+    return path
+
+
 def _split_of(filename: str, say) -> str:
     low = filename.lower()
     for s in ("train", "valid", "test"):
@@ -69,7 +80,7 @@ class KSTrajectoryDatasetFromFile(Dataset):
 
     def __init__(self, filename, saved_folder, reduced_batch=1, reduced_resolution=1, reduced_resolution_t=1,
                  use_low_pass_filter=False, lowpass_cutoff_ratio=1.0, num_samples_max=-1, **kwargs):
-        path = os.path.join(os.path.abspath(saved_folder), filename)
+        path = _resolve(saved_folder, filename)
         self.split = _split_of(filename, print)
         with Store(path) as f:
             group = _open_group(f, self.split)
@@ -100,7 +111,7 @@ class KSMarkovDataset(Dataset):
     def __init__(self, filename, saved_folder, reduced_batch=1, reduced_resolution=1, reduced_resolution_t=1,
                  use_low_pass_filter=False, lowpass_cutoff_ratio=1.0, num_samples_max=-1, **kwargs):
         self.use_low_pass_filter, self.lowpass_cutoff_ratio = use_low_pass_filter, lowpass_cutoff_ratio
-        path = os.path.join(os.path.abspath(saved_folder), filename)
+        path = _resolve(saved_folder, filename)
         self.split = _split_of(filename, print)
         with Store(path) as f:
             group = _open_group(f, self.split)

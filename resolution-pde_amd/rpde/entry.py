@@ -153,7 +153,10 @@ def run(dims: int, argv=None):
             # whole test trajectories of the file [T, X], physical units: encode the start, roll in normalised space
             # (decode with y-statistics, re-encode with x-statistics between steps), compare in physical units
             steps = min(steps, int(rollout_set[0].shape[0]) - 1)
-            mine = [rollout_set[i] for i in range(rank, len(rollout_set), world)]              # this rank's trajectories
+            # (a multi-resolution loader hands over test trajectories of every file resolution: like the mixed test
+            #  split above, the rollout is evaluated on the highest one)
+            full = [rollout_set[i] for i in range(len(rollout_set)) if int(rollout_set[i].shape[-1]) == top_res]
+            mine = full[rank::world]                                                             # this rank's trajectories
             phys = (torch.stack(mine)[:, :steps + 1] if mine else torch.zeros(0, steps + 1, top_res)).to(device)
             if min_data is not None:
                 enc = lambda t: (t - min_data) / (max_data - min_data)                           # noqa: E731

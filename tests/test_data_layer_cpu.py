@@ -289,3 +289,148 @@ def test_store_groups(tmp_path):
     open(os.path.join(tmp_path, "a.txt"), "w").close()
     with pytest.raises(ValueError, match="Unsupported file extension"):
         Store(os.path.join(tmp_path, "a.txt"))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# KS / Burgers true multi-resolution loaders ("parity unpinned": the reference reads them through h5py only).  The
+# expectations below restate the reference's rules independently of the implementation: file-order split before
+# anything else, seeded draws (random_seed + resolution + split_idx without replacement on the file leg,
+# + 10000 with replacement on the downsample leg), which time steps pair up, what the rollout set holds, the arity.
+# ---------------------------------------------------------------------------------------------------------------
+def _expected_file_leg(u, split, target, resolution, seed=42, ratio=(0.8, 0.1, 0.1)):
+    n = u.shape[0]
+    a, b = int(n * ratio[0]), int(n * ratio[0]) + int(n * ratio[1])
+    part = {"train": u[:a], "val": u[a:b], "test": u[b:]}[split]
+    k = {"train": 0, "val": 1, "test": 2}[split]
+    if 0 < target < part.shape[0]:
+        take = int(target * ratio[k])
+        if take <= 0:
+            return None
+        np.random.seed(seed + resolution + k)
+        part = part[np.random.choice(part.shape[0], take, replace=False)]
+    return part
+
+
+def test_ks_true_multires_dataset(tmp_path):
+    from dataloaders.ks_naive_true_multires import (KSTrueMultiResMarkovDataset, extract_ks_test_trajectories_for_rollout,
+                                                    ks_true_multires_markov_dataset)
+    from utils.low_pass_filter import lowpass_filter_1d
+    d = str(tmp_path)
+    sub = "visc_0.05_L64.0_lmax8_et5.0_nte51_nt51"
+    data = {}
+    for res, n, seed in ((64, 40, 1), (32, 20, 2)):
+        os.makedirs(os.path.join(d, f"res_{res}", sub))
+        data[res], _ = _ks_archive(os.path.join(d, f"res_{res}", sub, "KS_train_2048.npz"), "train", n=n, t=6, x=res, seed=seed)
+    mres = {64: 20, 32: 400, 16: 0, 128: 7}                   # 128: no such file -> skipped with a warning; 16: target 0
+    out = ks_true_multires_markov_dataset(d, data_mres_size=mres, add_res=[16, 64], add_res_samples={16: 30},
+                                          downsample_from_res=64)
+    assert len(out) == 6
+    tr, va, te, roll, xn, yn = out
+    # file leg, train: 64 -> draw of int(20 * 0.8) = 16 of the first 32 trajectories; 32 -> all 16 (400 > 16)
+    e64, e32 = _expected_file_leg(data[64], "train", 20, 64), _expected_file_leg(data[32], "train", 400, 32)
+    assert e64.shape[0] == 16 and e32.shape[0] == 16
+    # downsample leg, train: int(30 * 0.8) = 24 draws WITH replacement from the first 32 trajectories of the 64 file,
+    # every 4th point; target 64 >= base size: skipped
+    np.random.seed(42 + 16 + 0 + 10000)
+    e16 = data[64][:32][np.random.choice(32, 24, replace=True)][:, :, ::4]
+    raw = tr.dataset
+    assert len(raw) == (16 + 16 + 24) * 5                      # KS pairs keep the first step: T - 1 = 5 per trajectory
+    info = raw.get_resolution_info()
+    assert info[0] == "64_file" and info[16 * 5] == "32_file" and info[-1] == "16_downsampled_naive"
+    x, y = raw[5 * 3 + 2]
+    np.testing.assert_array_equal(x.numpy(), e64[3, 2][None]); np.testing.assert_array_equal(y.numpy(), e64[3, 3][None])
+    x, y = raw[16 * 5 + 5 * 15 + 4]
+    np.testing.assert_array_equal(x.numpy(), e32[15, 4][None]); np.testing.assert_array_equal(y.numpy(), e32[15, 5][None])
+    x, y = raw[32 * 5 + 5 * 7]
+    assert x.shape == (1, 16)
+    np.testing.assert_array_equal(x.numpy(), e16[7, 0][None]); np.testing.assert_array_equal(y.numpy(), e16[7, 1][None])
+    # statistics: one mean / std over every value of the training pairs
+    allx = np.concatenate([e64[:, :-1].ravel(), e32[:, :-1].ravel(), e16[:, :-1].ravel()])
+    assert xn.mean == pytest.approx(float(allx.mean()), rel=1e-5, abs=1e-6)
+    assert xn.std == pytest.approx(float(torch.from_numpy(allx).std()), rel=1e-5)
+    nx, _ = tr[0]
+    np.testing.assert_allclose(nx.numpy(), (e64[0, 0][None] - xn.mean) / (xn.std + 1e-8), rtol=1e-5, atol=1e-6)
+    # val / test splits and the rollout set (test trajectories of the file leg, same draw, whole and raw)
+    # (the draw only happens when the target is SMALLER than the split: 20 > 4 validation trajectories -> all four)
+    assert len(va.dataset) == (4 + 2 + int(30 * 0.1)) * 5
+    t64, t32 = _expected_file_leg(data[64], "test", 20, 64), _expected_file_leg(data[32], "test", 400, 32)
+    assert len(roll) == t64.shape[0] + t32.shape[0] == 4 + 2
+    np.testing.assert_array_equal(roll[1].numpy(), t64[1]); np.testing.assert_array_equal(roll[4].numpy(), t32[0])
+    assert roll.get_trajectory_info(4) == {"resolution": 32, "original_index": 0, "source": "res_32_file"}
+    trajs, tinfo = extract_ks_test_trajectories_for_rollout(d, data_mres_size={64: 20}, reduced_resolution_t=2)
+    assert len(trajs) == 4 and trajs[0].shape == (3, 64) and tinfo[0]["resolution"] == 64
+    # low-pass leg keeps the base grid (Q14); reductions stride samples and time before the split on the file leg
+    lp = KSTrueMultiResMarkovDataset(d, data_mres_size={64: 40}, add_res=[16], add_res_samples={16: 10}, use_low_pass_filter=True,
+                                     lowpass_cutoff_ratio=0.5, split="train")
+    assert lp[len(lp) - 1][0].shape == (1, 64) and lp.get_resolution_info()[-1] == "16_downsampled_lowpass"
+    np.random.seed(42 + 16 + 10000)
+    drawn = data[64][:32][np.random.choice(32, 8, replace=True)]
+    want = lowpass_filter_1d(torch.from_numpy(drawn).float(), cutoff_ratio=(16 / 64) * 0.5)
+    np.testing.assert_allclose(lp[32 * 5][0].numpy(), want[0, 0][None].numpy(), atol=1e-6)
+    red = KSTrueMultiResMarkovDataset(d, data_mres_size={64: 40}, reduced_batch=2, reduced_resolution_t=2, split="val")
+    assert len(red) == 2 * 2 and red.downsample_from_res == 64
+    np.testing.assert_array_equal(red[1][1].numpy(), data[64][::2, ::2][16, 2][None])
+    # arity follows normalization_type, also without statistics; minmax works on mixed grids
+    out8 = ks_true_multires_markov_dataset(d, data_mres_size={64: 40, 32: 20}, normalization_type="minmax")
+    assert len(out8) == 8
+    lo, hi = out8[4], out8[5]
+    assert lo == float(min(data[64][:32, :-1].min(), data[32][:16, :-1].min())) and hi >= lo
+    assert float(out8[0][0][0].min()) >= 0.0
+    none6 = ks_true_multires_markov_dataset(d, data_mres_size={64: 40}, data_normalizer=False)
+    assert len(none6) == 6 and none6[4] is None and none6[0][0][0].shape == (1, 64)
+    with pytest.raises(ValueError, match="Invalid normalization_type"):
+        ks_true_multires_markov_dataset(d, data_mres_size={64: 40}, normalization_type="unit_gaussian")
+    with pytest.raises(ValueError, match="Invalid split"):
+        KSTrueMultiResMarkovDataset(d, data_mres_size={64: 40}, split="holdout")
+    # group discovery: 'train', else the only group, else a group named like the data; else an error
+    odd = os.path.join(d, "res_8", sub)
+    os.makedirs(odd)
+    np.savez(os.path.join(odd, "KS_train_2048.npz"), **{"meta/info": np.zeros(1), "pde_stuff/pde_6-8": data[32][:, :, :8]})
+    assert len(KSTrueMultiResMarkovDataset(d, data_mres_size={8: 100})) == 16 * 5
+    np.savez(os.path.join(odd, "KS_train_2048.npz"), **{"a/pde_6-8": data[32][:, :, :8], "b/x": np.zeros(1)})
+    with pytest.raises(ValueError, match="Could not find data group"):
+        KSTrueMultiResMarkovDataset(d, data_mres_size={8: 100})
+
+
+def test_burger_true_multires_dataset(tmp_path):
+    from dataloaders.burger_naive_true_multires import (H5pyTrueMultiResMarkovDataset, burger_true_multires_markov_dataset,
+                                                        extract_burgers_test_trajectories_for_rollout)
+    d = str(tmp_path)
+    rng = np.random.default_rng(9)
+    data = {}
+    for res, n in ((128, 30), (64, 50)):
+        os.makedirs(os.path.join(d, f"burgers_{res}_0.001"))
+        data[res] = rng.standard_normal((n, 7, res)).astype(np.float32)
+        np.savez(os.path.join(d, f"burgers_{res}_0.001", "1D_Burgers_Sols_Nu0.001.npz"), tensor=data[res])
+    out = burger_true_multires_markov_dataset(d, data_mres_size={128: 10, 64: 1000, 256: 5}, add_res=[32], add_res_samples={32: 20})
+    assert len(out) == 8                                       # default normalisation: minmax
+    tr, va, te, roll, lo_x, hi_x, lo_y, hi_y = out
+    e128, e64 = _expected_file_leg(data[128], "train", 10, 128), _expected_file_leg(data[64], "train", 1000, 64)
+    assert e128.shape[0] == 8 and e64.shape[0] == 40
+    np.random.seed(42 + 32 + 0 + 10000)                        # base: the highest resolution with samples = 128
+    e32 = data[128][:24][np.random.choice(24, 16, replace=True)][:, :, ::4]
+    raw = tr.dataset
+    assert raw.downsample_from_res == 256 or raw.downsample_from_res == 128
+    assert len(raw) == (8 + 40 + (16 if raw.downsample_from_res == 128 else 0)) * 5     # pairs drop the first step: T - 2 = 5
+    x, y = raw[5 * 2 + 1]
+    np.testing.assert_array_equal(x.numpy(), e128[2, 2][None]); np.testing.assert_array_equal(y.numpy(), e128[2, 3][None])
+    # (256 has a non-zero target and is the highest named resolution: it is the auto-selected base although it has no
+    #  file -- the reference's rule -- so the downsample leg is empty here; naming the base gives the 32-point samples)
+    assert raw.downsample_from_res == 256 and "32_downsampled_naive" not in raw.get_resolution_info()
+    out = burger_true_multires_markov_dataset(d, data_mres_size={128: 10, 64: 1000}, add_res=[32], add_res_samples={32: 20},
+                                              normalization_type="simple")
+    assert len(out) == 6
+    tr, va, te, roll, xn, yn = out
+    raw = tr.dataset
+    assert raw.downsample_from_res == 128 and len(raw) == (8 + 40 + 16) * 5
+    x, y = raw[48 * 5 + 5 * 5 + 3]
+    np.testing.assert_array_equal(x.numpy(), e32[5, 4][None]); np.testing.assert_array_equal(y.numpy(), e32[5, 5][None])
+    t128, t64 = _expected_file_leg(data[128], "test", 10, 128), _expected_file_leg(data[64], "test", 1000, 64)
+    assert len(roll) == t128.shape[0] + t64.shape[0] == 3 + 5 and roll[0].shape == (7, 128)      # 10 > 3: no draw
+    np.testing.assert_array_equal(roll[0].numpy(), t128[0]); np.testing.assert_array_equal(roll[7].numpy(), t64[4])
+    allx = np.concatenate([e128[:, 1:-1].ravel(), e64[:, 1:-1].ravel(), e32[:, 1:-1].ravel()])
+    assert xn.mean == pytest.approx(float(allx.mean()), rel=1e-5, abs=1e-6)
+    trajs, _ = extract_burgers_test_trajectories_for_rollout(d, data_mres_size={64: 1000})
+    assert len(trajs) == 5
+    assert len(H5pyTrueMultiResMarkovDataset(d, data_mres_size={64: 1000}, split="val")) == 5 * 5
+    assert len(H5pyTrueMultiResMarkovDataset(d, data_mres_size={512: 3})) == 0          # no file: warning, empty set

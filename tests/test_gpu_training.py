@@ -335,6 +335,62 @@ def test_main_2d_on_true_multires_files(gpu_device, tmp_path, capsys, eval_file)
     assert np.isfinite(l2) and set(run.last["resolution_rel_l2"]) == {32}
 
 
+def test_main_1d_on_ks_true_multires_files(gpu_device, tmp_path, capsys):
+    """dataset=ks/ks_naive_true_mres: one file per resolution in the reference's directory layout plus stride-subsampled
+    samples -> three resolution groups in one FFNO1D run; the all-resolution evaluation reads the top file through
+    the single-file loader (eval_dataset_target), the rollout set comes from the multi-resolution loader"""
+    import json
+    import numpy as np
+    from rpde.entry import run
+    sub = "visc_0.075_L64.0_lmax8_et5.0_nte51_nt51"
+    for res, n, seed in ((64, 30, 1), (32, 20, 2)):
+        (tmp_path / f"res_{res}" / sub).mkdir(parents=True)
+        u = (_smooth_1d(n, res, 8, seed) * 2.0 + 0.5).astype(np.float32)
+        np.savez(tmp_path / f"res_{res}" / sub / "KS_train_2048.npz", **{f"train/pde_9-{res}": u})
+    # the evaluation loader (ks_markov_dataset) reads one file per split from the top resolution's directory, under
+    # its default names KS_valid.h5 / KS_test.h5 -- here their .npz stand-ins
+    for split, name, seed in (("valid", "KS_valid.npz", 5), ("test", "KS_test.npz", 6)):
+        np.savez(tmp_path / "res_64" / sub / name, **{f"{split}/pde_9-64": (_smooth_1d(6, 64, 8, seed) * 2.0 + 0.5).astype(np.float32)})
+    l2 = run(1, ["model=ffno_1d/ffno_1d", "dataset=ks/ks_naive_true_mres", f"dataset.dataset_params.saved_folder={tmp_path}",
+                 "dataset.dataset_params.data_mres_size={64: 30, 32: 20}", "dataset.dataset_params.add_res=[16]",
+                 "dataset.dataset_params.add_res_samples={16: 10}", "dataset.dataset_params.downsample_from_res=64",
+                 "dataset.dataset_params.eval_filename=KS_train_2048.npz",
+                 f"dataset.dataset_params.eval_saved_folder={tmp_path}/res_64/{sub}", "dataset.original_res=64",
+                 "dataset.max_test_resolution=64", "dataset.rollout_steps=4", "model.width=16", "model.n_layers=2",
+                 "model.n_modes=8", "model.factor=2", "training.epochs=4", "training.batch_size=8",
+                 "training.learning_rate=0.003", "training.use_normalizer=true", f"checkpoint_dir={tmp_path}"])
+    out = capsys.readouterr().out
+    head = json.loads([ln for ln in out.splitlines() if '"train_batches"' in ln][0])
+    # train split: 24 trajectories at 64, 16 at 32, 8 draws at 16; 8 pairs each (KS keeps the first step)
+    assert head["train_batches"] == (24 * 8) // 8 + (16 * 8) // 8 + (8 * 8) // 8
+    assert np.isfinite(l2) and all(np.isfinite(v) for v in run.last["rollout_rel_l2"].values())
+
+
+def test_main_1d_on_burgers_true_multires_files(gpu_device, tmp_path, capsys):
+    """dataset=burger/burger_naive_true_mres with the loader's "minmax" statistics on a mixed-grid training set (the
+    reference's DataLoader-based statistics would refuse it) and FNO1d"""
+    import json
+    import numpy as np
+    from rpde.entry import run
+    for res, n, seed in ((64, 30, 3), (32, 20, 4)):
+        (tmp_path / f"burgers_{res}_0.001").mkdir()
+        u = (_smooth_1d(n, res, 7, seed) * 2.0 + 0.5).astype(np.float32)
+        np.savez(tmp_path / f"burgers_{res}_0.001" / "1D_Burgers_Sols_Nu0.001.npz", tensor=u,
+                 **{"x-coordinate": np.linspace(0, 1, res, dtype=np.float32)})
+    l2 = run(1, ["model=fno_1d/fno_1d", "dataset=burger/burger_naive_true_mres", f"dataset.dataset_params.saved_folder={tmp_path}",
+                 "dataset.dataset_params.viscosity=0.001", "dataset.dataset_params.data_mres_size={64: 30, 32: 20}",
+                 "dataset.dataset_params.add_res=null", "dataset.dataset_params.downsample_from_res=64",
+                 "dataset.dataset_params.normalization_type=minmax",
+                 "dataset.dataset_params.eval_filename=1D_Burgers_Sols_Nu0.001.npz",
+                 f"dataset.dataset_params.eval_saved_folder={tmp_path}/burgers_64_0.001", "dataset.original_res=64",
+                 "dataset.max_test_resolution=64", "dataset.rollout_steps=3", "model.width=16", "model.modes=8",
+                 "training.epochs=4", "training.batch_size=8", "training.learning_rate=0.003", f"checkpoint_dir={tmp_path}"])
+    out = capsys.readouterr().out
+    head = json.loads([ln for ln in out.splitlines() if '"train_batches"' in ln][0])
+    assert head["train_batches"] == (24 * 6) // 8 + (16 * 6) // 8          # Burgers pairs drop the first step: T - 2 = 6
+    assert np.isfinite(l2) and set(run.last["resolution_rel_l2"]) == {32, 64}
+
+
 def test_warm_plans_leaves_no_plan_to_build_inside_a_step(gpu_device):
     """rpde.ops.warm_plans: after it has seen the run's grids, forward + backward at those grids add nothing to
     the plan cache (no hipMalloc / stream sync inside a training step); an unseen grid does"""
