@@ -380,22 +380,27 @@ __global__ __launch_bounds__(COL_MIX_THREADS) void k_col_mix_synthesis(const flo
     col_sm[(2 * r + 1) * KP + ky] = ai;
   }
   __syncthreads();
-  // four output rows per thread at a time (mu, mu + 256, ..): a row of the mixed block then feeds 4 kp multiply-adds
-  for (int mu0 = tid; mu0 < M2; mu0 += 4 * nth) {
+  // four CONSECUTIVE output rows per thread: a row of the mixed block (LDS broadcast) feeds 4 kp multiply-adds, the table
+  // (transposed, [2R][2M]) is read 16 bytes per thread and row -- 48 loads per thread instead of 192 -- and the 4 kp
+  // results leave as one contiguous run.  (M2 = 2M is a multiple of 4 whenever M is even; odd M takes the tail loop.)
+  const int M4 = M2 & ~3;
+  for (int mu0 = 4 * tid; mu0 < M4; mu0 += 4 * nth) {
     float acc[4][KP];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int k = 0; k < KP; ++k) acc[j][k] = 0.f;
-    int mus[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) mus[j] = min(mu0 + j * nth, M2 - 1);
-    // (table read transposed, [2R][2M]: consecutive lanes = consecutive output rows)
+    const bool vec = ((M2 & 3) == 0);                  // rows of the transposed table are 16-byte aligned
 #pragma unroll 12
     for (int rho = 0; rho < R2; ++rho) {
       float f[4];
+      if (vec) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fs_t + (long)rho * M2 + mu0);
+        f[0] = f4.x; f[1] = f4.y; f[2] = f4.z; f[3] = f4.w;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f[j] = fs_t[(long)rho * M2 + mus[j]];
+        for (int j = 0; j < 4; ++j) f[j] = fs_t[(long)rho * M2 + mu0 + j];
+      }
       const float4* row = reinterpret_cast<const float4*>(col_sm + rho * KP);
 #pragma unroll
       for (int q = 0; q < KP / 4; ++q) {
@@ -407,15 +412,24 @@ __global__ __launch_bounds__(COL_MIX_THREADS) void k_col_mix_synthesis(const flo
         }
       }
     }
+    float4* dst = reinterpret_cast<float4*>(t1 + (bo * M2 + mu0) * KP);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int mu = mu0 + j * nth;
-      if (mu < M2) {
-        float4* dst = reinterpret_cast<float4*>(t1 + (bo * M2 + mu) * KP);
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int q = 0; q < KP / 4; ++q) dst[q] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
-      }
+      for (int q = 0; q < KP / 4; ++q)
+        dst[j * (KP / 4) + q] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+  }
+  for (int mu = M4 + tid; mu < M2; mu += nth) {        // at most three rows (odd M)
+    float acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) acc[k] = 0.f;
+    for (int rho = 0; rho < R2; ++rho) {
+      const float f = fs_t[(long)rho * M2 + mu];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) acc[k] = fmaf(f, col_sm[rho * KP + k], acc[k]);
     }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) t1[(bo * M2 + mu) * KP + k] = acc[k];
   }
 }
 
