@@ -1201,10 +1201,13 @@ size_t fused2d_img_bytes(long lines, int R) { return (size_t)lines * 4 * h2_bloc
     }                                                                                           \
   } while (0)
 
-// RPDE_ANA_SQ=0: keep the two-read analysis kernel for every shape (A/B, tests)
+// RPDE_ANA_SQ=0: keep the two-read analysis kernel for every shape; =2: the one-pass kernel for every square grid (A/B,
+// tests).  Default: from 128^2 up -- at 64^2 only 64 of a group's 256 waves have a column to own and the two-read
+// kernel is faster (train step at B = 32: 3.13 vs 3.21 ms, at B = 8: 1.92 vs 2.07 ms).
 static bool ana_sq_ok(int M, int N, int cus) {
-  if (const char* e = getenv("RPDE_ANA_SQ")) if (e[0] == '0') return false;
-  return M == N && cus >= 256;
+  const char* e = getenv("RPDE_ANA_SQ");
+  if (e && e[0] == '0') return false;
+  return M == N && cus >= 256 && (M >= 128 || (e && e[0] == '2'));
 }
 
 int fused2d_analysis(const float* x, float* spec_y, float* spec_x, float* amax_y, float* amax_x, const rpde_plan* py,

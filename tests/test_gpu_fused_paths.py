@@ -351,14 +351,18 @@ def test_round3_spectral_kernels_over_batch_grid_and_mode_variants(gpu_device, s
         (out * g + skip * (0.5 * g)).sum().backward()          # the skip gradient is added by the adjoint synthesis
         return out.detach(), xs.grad, a.grad, b.grad
 
-    fused = run()
     with _env(RPDE_FUSED_SPECTRAL="0"):
         plain = run()
-    for name, p, q in zip(("out", "dx", "dWy", "dWx"), fused, plain):
-        assert torch.isfinite(p).all(), name
-        # per sample for the fields (a sample 1e6 smaller than its neighbour must keep its own accuracy)
-        if name in ("out", "dx"):
-            worst = max(_rel(p[i], q[i]) for i in range(B))
-            assert worst < 3e-6, (name, worst)
-        else:
-            assert _rel(p, q) < 3e-6, (name, _rel(p, q))
+    # default dispatch (one-pass analysis from 128^2 up, two-read kernel below), each analysis kernel forced on every
+    # square grid (RPDE_ANA_SQ=2 / 0)
+    for leg in ({}, {"RPDE_ANA_SQ": "2"}, {"RPDE_ANA_SQ": "0"}):
+        with _env(**leg):
+            fused = run()
+        for name, p, q in zip(("out", "dx", "dWy", "dWx"), fused, plain):
+            assert torch.isfinite(p).all(), (leg, name)
+            # per sample for the fields (a sample 1e6 smaller than its neighbour must keep its own accuracy)
+            if name in ("out", "dx"):
+                worst = max(_rel(p[i], q[i]) for i in range(B))
+                assert worst < 3e-6, (leg, name, worst)
+            else:
+                assert _rel(p, q) < 3e-6, (leg, name, _rel(p, q))
