@@ -357,22 +357,28 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_h2(const Ana
 //     partial y-axis spectra are summed through LDS (two halves of the channels, 48 KB).
 // Each step reads its 2 MB row block once by rows and once by columns, within microseconds of each other, on one
 // XCD.  No inter-workgroup synchronisation: the workgroups of a group run the same schedule and drift only by
-// scheduling noise.  Needs M = N (one table for both axes) and 32 workgroups per group.
+// scheduling noise.  Needs M = N (one table for both axes).
+// Grids below 256: a row has n / 32 < 8 chunks, so a workgroup takes rpw = 8 / (n / 32) rows of the block (wave ->
+// (row, chunk)) and a group is 32 / rpw workgroups -- 8 * 32 / rpw waves >= n columns -- so that at 128^2 and 64^2 every
+// wave has a column and a chunk as well; the chip then holds 8 rpw groups, each walking through its own samples
+// (with one row per workgroup whatever the grid, 128^2 ran at 81 us for a quarter of the bytes of 256^2's 212 us).
 struct AnaSqP {
   const float* x; const char* timg;
   float* spec_y; float* spec_x; float* amax_y; float* amax_x;
-  int B, n, ks, R, ng;
+  int B, n, ks, R, ng, rpw;
 };
 
 template <int MT>
 __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const AnaSqP P) {
   constexpr int TAB = ANA_MAXKS * MT * 2048, STG = ANA_WAVES * 8192, RED = ANA_WAVES * MT * 2 * 1024;
   __shared__ __attribute__((aligned(16))) char smem[TAB + STG + RED];         // 160 KB at MT = 3: all of it
-  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6, g = l >> 4, li = l & 15;
+  // (wave through readfirstlane: everything derived from it -- duties, wait counts -- is then uniform for the compiler
+  //  too: scalar branches instead of exec masks, and the if / else chain of waits below is one the ISA test can follow)
+  const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = l >> 4, li = l & 15;
   char* const stage = smem + TAB + wave * 8192;
   // per-wave partial maxima of a row's spectrum: the last 32 bytes of the reduction area (the landing zone of the
   // partial spectra ends 16 KB before it)
-  float* const wmax = reinterpret_cast<float*>(smem + TAB + STG + RED - 32);
+  float* const wmax = reinterpret_cast<float*>(smem + TAB + STG + RED - 256);     // [row of the workgroup][wave]
   const int q = li >> 2, pp = li & 3;
   const int tsw = ((q >> 1) & 1) | ((g & 1) << 1);
   const int trow = (8 * g + q) * 128 + pp * 8;
@@ -382,11 +388,14 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
   const int xg = blockIdx.x % P.ng, jw = blockIdx.x / P.ng, gw = jw * ANA_WAVES + wave;
   const int nsamp = (P.B - xg + P.ng - 1) / P.ng;
   const long units = (long)nsamp * steps;           // (sample, row block) pairs of this group, in order
-  const bool has_x = gw < n, has_y = wave < steps;
+  const int rpw = P.rpw, yr = wave / steps, yc = wave - yr * steps;      // this wave's row of the workgroup's rows, its chunk
+  const bool has_x = gw < n, has_y = wave < rpw * steps;
+  if (units <= 0) return;                           // (more groups than samples)
   {
     const uint4* src = reinterpret_cast<const uint4*>(P.timg);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     for (int i = tid; i < steps * MT * 128; i += 64 * ANA_WAVES) dst[i] = src[i];
+    if (tid < 64) wmax[tid] = 0.f;
     __syncthreads();
   }
   const long rowf = (long)n * 64;                   // floats per row of the field
@@ -396,26 +405,27 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
   // phase ago, and for the spectrum stores in between -- the prefetch distance shrinks from a unit to nothing (this
   // kernel ran at 219 us, latency-bound).  The queue is in order: behind the x chunk of unit u there are always the 8
   // loads of the y chunk of u (and some stores), behind the y chunk of u the 8 loads of the x chunk of u + 1; so
-  // vmcnt(8) is enough in both places.  Every wave with a duty issues exactly 8 loads per phase (past the end: a
-  // clamped re-read), so the count holds; a wave with only one duty waits for zero.
+  // vmcnt(8) is enough in both places.  Every wave issues exactly 8 loads per phase (past the end: a
+  // clamped re-read; without a duty: a neighbour's chunk), so the count holds for all.
   auto gload = [](const float* p) {
     f32x4v v;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return v;
   };
+  // (a wave without a column or without a chunk -- grids that are no power of two -- loads a neighbour's: every wave
+  //  issues the same 16 loads per unit and the counts below hold for all)
+  const int gwc = has_x ? gw : n - 1, yrc = has_y ? yr : 0, ycc = has_y ? yc : 0;
   auto issue_x = [&](f32x4v (&buf)[8], long u) {    // column gw, rows of block t: lane (g, li) takes rows 4i + g
-    if (!has_x) return;
     u = u < units ? u : units - 1;
     const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
-    const float* q0 = P.x + (((long)(xg + P.ng * sb) * n + 32 * t + g) * n + gw) * 64 + li * 4;
+    const float* q0 = P.x + (((long)(xg + P.ng * sb) * n + 32 * t + g) * n + gwc) * 64 + li * 4;
 #pragma unroll
     for (int i = 0; i < 8; ++i) buf[i] = gload(q0 + i * 4 * rowf);
   };
-  auto issue_y = [&](f32x4v (&buf)[8], long u) {    // row 32 t + jw, points 32 wave ..: lane (g, li) takes points 4i + g
-    if (!has_y) return;
+  auto issue_y = [&](f32x4v (&buf)[8], long u) {    // row 32 t + rpw jw + yr, points 32 yc ..: lane (g, li) takes points 4i + g
     u = u < units ? u : units - 1;
     const int sb = (int)(u / steps), t = (int)(u - (long)sb * steps);
-    const float* q0 = P.x + (((long)(xg + P.ng * sb) * n + 32 * t + jw) * n + 32 * wave + g) * 64 + li * 4;
+    const float* q0 = P.x + (((long)(xg + P.ng * sb) * n + 32 * t + rpw * jw + yrc) * n + 32 * ycc + g) * 64 + li * 4;
 #pragma unroll
     for (int i = 0; i < 8; ++i) buf[i] = gload(q0 + i * 256);
   };
@@ -425,17 +435,41 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
   // maximum written by wave 0) -- with the stores counted in, a wave no longer waits for their acknowledgement before
   // it may touch data that arrived long ago (1.2-1.7 K of 13 K cycles per step).
   int nst_wave = 0;
-  for (int e = 64 * wave; e < MT * 4 * 64; e += 64 * ANA_WAVES) nst_wave += (16 * (e >> 8) + ((e >> 6) & 3)) < P.R ? 1 : 0;
+  for (int e = 64 * wave; e < rpw * MT * 256; e += 64 * ANA_WAVES) {
+    const int rem = e % (MT * 256);
+    nst_wave += (16 * (rem >> 8) + ((rem >> 6) & 3)) < P.R ? 1 : 0;
+  }
   if (wave == 0 && P.amax_y) ++nst_wave;
-  auto landed = [&](f32x4v (&buf)[8], bool other_duty, bool stores_behind) {
-    const int nst = stores_behind ? nst_wave : 0;        // (the very first chunk has only the other axis's loads behind it)
-#define RPDE_LANDED(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])::"memory")
-    if (!other_duty) { RPDE_LANDED(0); }
-    else if (nst <= 0) { RPDE_LANDED(8); }
-    else if (nst == 1) { RPDE_LANDED(9); }
-    else if (nst == 2) { RPDE_LANDED(10); }
-    else { RPDE_LANDED(11); }
-#undef RPDE_LANDED
+  nst_wave = __builtin_amdgcn_readfirstlane(nst_wave);
+  // ONE statement per wait, the choice of the count inside it (scalar compare + branch on nst): the chunk's registers
+  // pass through it as tied operands -- that is what orders their uses behind the wait -- and with one statement per
+  // alternative count the register allocator gave the four statements' operands other registers than the loads' and
+  // copied in front of the wait, i.e. read registers whose loads were in flight (seen in the MT = 1 instance;
+  // tests/test_isa_pending_loads_cpu.py follows the `landed` comment, which names the registers).  The very first
+  // chunks have no stores behind them: the loop waits for everything before its first unit instead.
+  auto landed = [&](f32x4v (&buf)[8]) {
+    asm volatile(
+        "s_cmp_lt_u32 %8, 2\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_cmp_eq_u32 %8, 2\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_waitcnt vmcnt(11)\n\t"
+        "s_branch 4f\n"
+        "2:\n\t"
+        "s_waitcnt vmcnt(10)\n\t"
+        "s_branch 4f\n"
+        "1:\n\t"
+        "s_cmp_eq_u32 %8, 1\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_waitcnt vmcnt(8)\n\t"
+        "s_branch 4f\n"
+        "3:\n\t"
+        "s_waitcnt vmcnt(9)\n"
+        "4:\n\t"
+        "s_nop 0 ; landed %0 %1 %2 %3 %4 %5 %6 %7"
+        : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])
+        : "s"(nst_wave)
+        : "memory", "scc");
   };
   // one 32-point chunk into accumulators that stay in scaled units for the whole line (k_dft_analysis_h2's scheme)
   auto process = [&](f32x4v (&buf)[8], int s, f32x4v (&tot)[MT][4], int& line_E) {
@@ -477,7 +511,6 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
       }
     }
   };
-  auto mfma_chunk = [&](int, f32x4v (&)[MT][4]) {};
 
   f32x4v totx[MT][4], toty[MT][4];
   int Ex = 0;
@@ -503,6 +536,12 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
     // (x first.  The other order -- whole 64 KB rows going to HBM, the x axis's 256-byte pieces finding them in L2 -- was
     //  measured: same time, but 604 instead of 553 MB fetched per launch)
     // ---- x axis: this wave's column, rows of block t ----
+    // EVERY wave waits for its chunk, with or without a duty: once the asm statement has returned the compiler takes
+    // the registers for filled, and where the values are not used it hands the registers to something else -- here the
+    // 64-bit division of the next address computation -- which a load still in flight then overwrites (found as a
+    // memory-aperture fault at 96^2 in training, never in the tests: a wave without a column skipped the wait)
+    if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (no stores behind the first chunks yet)
+    landed(bx);
     if (has_x) {
       if (t == 0) {
 #pragma unroll
@@ -511,11 +550,11 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
           for (int nt = 0; nt < 4; ++nt) totx[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         Ex = 0;
       }
-      landed(bx, has_y, u > 0);
       FSTAMP(0, sq0 + 8);
       process(bx, t, totx, Ex);
-      issue_x(bx, u + 1);
-      mfma_chunk(t, totx);
+    }
+    issue_x(bx, u + 1);                               // (every wave, with or without a column: the counts rely on it)
+    if (has_x) {
       if (t == steps - 1) {
         const long z = (long)b * n + gw;
         float* __restrict__ sp = P.spec_x + z * (long)P.R * 64;
@@ -538,21 +577,19 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
     }
     // ---- y axis: row 32 t + jw of the block; this wave's chunk of it, then the sum over the chunks ----
     float invy = 0.f;
+    landed(by);
     if (has_y) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) toty[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
       int Ey = 0;
-      landed(by, has_x, u > 0);
       FSTAMP(0, sq0 + 1);
-      process(by, wave, toty, Ey);
-      issue_y(by, u + 1);
-      mfma_chunk(wave, toty);
+      process(by, yc, toty, Ey);
       invy = __uint_as_float((unsigned)(Ey - 14 - H2_TABLE_EXP) << 23);
     }
-    const long zy = (long)b * n + 32 * t + jw;
-    float* __restrict__ spy = P.spec_y + zy * (long)P.R * 64;
+    issue_y(by, u + 1);
+    const long zy = (long)b * n + 32 * t + rpw * jw;      // the first of this workgroup's rows
     // the eight partial spectra of the row -> one: every wave is done with its staging area until the next step, so the
     // staging areas + the reduction area together take all partials at once ([wave][mt][nt][lane] float4, 4 MT KB per
     // wave), one pass, two barriers
@@ -575,35 +612,37 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
     FSTAMP(0, sq0 + 4);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     FSTAMP(0, sq0 + 5);
-    float am = 0.f;
-    for (int e = tid; e < MT * 4 * 64; e += 64 * ANA_WAVES) {
-      const int mt = e >> 8, j = (e >> 6) & 3, ln = e & 63;
+    for (int e = tid; e < rpw * MT * 256; e += 64 * ANA_WAVES) {            // (a wave's 64 items of a pass share the row)
+      const int rr = e / (MT * 256), rem = e - rr * (MT * 256);
+      const int mt = rem >> 8, j = (rem >> 6) & 3, ln = rem & 63;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int w2 = 0; w2 < ANA_WAVES; ++w2) {             // (all eight reads in flight; waves without a chunk wrote nothing)
-        if (w2 < steps) {
-          const float4 v = *reinterpret_cast<const float4*>(land + ((w2 * MT + mt) * 4 + j) * 1024 + ln * 16);
+      for (int c2 = 0; c2 < ANA_WAVES; ++c2) {             // (all reads in flight: the row's chunks sit in consecutive waves)
+        if (c2 < steps) {
+          const float4 v = *reinterpret_cast<const float4*>(land + (((rr * steps + c2) * MT + mt) * 4 + j) * 1024 + ln * 16);
           a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
       }
       const int row = 16 * mt + 4 * (ln >> 4) + j;
+      float am = 0.f;
       if (row < P.R) {
-        *reinterpret_cast<float4*>(spy + row * 64 + 4 * (ln & 15)) = a;
-        am = fmaxf(am, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        *reinterpret_cast<float4*>(P.spec_y + (zy + rr) * (long)P.R * 64 + row * 64 + 4 * (ln & 15)) = a;
+        am = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
       }
+      am = wave_max(am);
+      if (l == 0) wmax[rr * ANA_WAVES + wave] = fmaxf(wmax[rr * ANA_WAVES + wave], am);   // (its own 256 bytes behind the landing zone)
     }
-    am = wave_max(am);
-    if (l == 0) wmax[wave] = am;                                           // (its own 32 bytes behind the landing zone)
     FSTAMP(0, sq0 + 6);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the landing zone has been read: staging may be reused
     FSTAMP(0, sq0 + 7);
-    if (tid == 0 && P.amax_y) {
+    if (tid < rpw) {                                  // (the next step's maxima are written two barriers from here)
       float a8 = 0.f;
-      for (int i = 0; i < ANA_WAVES; ++i) a8 = fmaxf(a8, wmax[i]);
-      P.amax_y[zy] = a8;
+      for (int i = 0; i < ANA_WAVES; ++i) { a8 = fmaxf(a8, wmax[tid * ANA_WAVES + i]); wmax[tid * ANA_WAVES + i] = 0.f; }
+      if (P.amax_y) P.amax_y[zy + tid] = a8;
     }
     FSTAMP(0, sq0 + 9);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the re-reads past the end)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1201,13 +1240,13 @@ size_t fused2d_img_bytes(long lines, int R) { return (size_t)lines * 4 * h2_bloc
     }                                                                                           \
   } while (0)
 
-// RPDE_ANA_SQ=0: keep the two-read analysis kernel for every shape; =2: the one-pass kernel for every square grid (A/B,
-// tests).  Default: from 128^2 up -- at 64^2 only 64 of a group's 256 waves have a column to own and the two-read
-// kernel is faster (train step at B = 32: 3.13 vs 3.21 ms, at B = 8: 1.92 vs 2.07 ms).
+// RPDE_ANA_SQ=0: keep the two-read analysis kernel for every shape (A/B, tests).  Default: the one-pass kernel on every
+// square grid (with a workgroup's rows matched to the grid it is level with the two-read kernel at 64^2 and 128^2 for
+// B = 32 and ahead at B = 8: 2.03 vs 2.25 ms per training step at 64^2).
 static bool ana_sq_ok(int M, int N, int cus) {
   const char* e = getenv("RPDE_ANA_SQ");
   if (e && e[0] == '0') return false;
-  return M == N && cus >= 256 && (M >= 128 || (e && e[0] == '2'));
+  return M == N && cus >= 256;
 }
 
 int fused2d_analysis(const float* x, float* spec_y, float* spec_x, float* amax_y, float* amax_x, const rpde_plan* py,
@@ -1219,8 +1258,11 @@ int fused2d_analysis(const float* x, float* spec_y, float* spec_x, float* amax_y
     if (ana_sq_ok(M, N, cus) && py->h2_ana[adjoint] == px->h2_ana[adjoint]) {
       AnaSqP Q;
       Q.x = x; Q.timg = (const char*)py->h2_ana_p[adjoint]; Q.spec_y = spec_y; Q.spec_x = spec_x; Q.amax_y = amax_y; Q.amax_x = amax_x;
-      Q.B = B; Q.n = N; Q.ks = N / 32; Q.R = 2 * py->kp; Q.ng = B < 8 ? B : 8;
-      const dim3 grid(32 * Q.ng), blk(64 * ANA_WAVES);
+      Q.B = B; Q.n = N; Q.ks = N / 32; Q.R = 2 * py->kp;
+      Q.rpw = ANA_WAVES / Q.ks;                            // rows of a block per workgroup; 32 / rpw workgroups per group
+      const int wpg = 32 / Q.rpw;
+      Q.ng = B < 256 / wpg ? B : 256 / wpg;
+      const dim3 grid(wpg * Q.ng), blk(64 * ANA_WAVES);
       const int MTq = (Q.R + 15) / 16;
       if (MTq == 1) hipLaunchKernelGGL(k_dft_analysis_sq_h2<1>, grid, blk, 0, st, Q);
       else if (MTq == 2) hipLaunchKernelGGL(k_dft_analysis_sq_h2<2>, grid, blk, 0, st, Q);

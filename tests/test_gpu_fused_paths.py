@@ -330,9 +330,11 @@ def test_small_channel_conv_kernel(gpu_device, cin, cout, act_in, act_out):
 
 
 @pytest.mark.parametrize("shape", [(9, 64, 64, 20), (8, 128, 128, 12), (5, 64, 64, 16), (2, 64, 64, 24), (3, 128, 64, 8),
-                                   (1, 192, 192, 20), (17, 64, 64, 4), (2, 256, 256, 20)])
+                                   (1, 192, 192, 20), (17, 64, 64, 4), (2, 256, 256, 20), (3, 96, 96, 12), (2, 160, 160, 20),
+                                   (40, 32, 32, 8), (70, 64, 64, 20)])
 def test_round3_spectral_kernels_over_batch_grid_and_mode_variants(gpu_device, shape):
-    """the round-3 kernels (k_dft_analysis_sq_h2: XCD groups with uneven sample counts, grids of 64 .. 256; k_mix_h2 /
+    """the round-3 kernels (k_dft_analysis_sq_h2: XCD groups with uneven sample counts, grids of 32 .. 256 incl. those whose
+    rows do not fill a workgroup's eight waves, more groups than samples and fewer; k_mix_h2 /
     k_mix_wgrad_h2: every (K32, TG) operand layout incl. the packed tails; k_dft_synthesis3_h2: persistent tiles with
     1 .. many tiles per workgroup, with and without the skip gradient) against the per-GEMM path"""
     B, M, N, K = shape
@@ -353,9 +355,8 @@ def test_round3_spectral_kernels_over_batch_grid_and_mode_variants(gpu_device, s
 
     with _env(RPDE_FUSED_SPECTRAL="0"):
         plain = run()
-    # default dispatch (one-pass analysis from 128^2 up, two-read kernel below), each analysis kernel forced on every
-    # square grid (RPDE_ANA_SQ=2 / 0)
-    for leg in ({}, {"RPDE_ANA_SQ": "2"}, {"RPDE_ANA_SQ": "0"}):
+    # default dispatch (one-pass analysis on every square grid), the two-read analysis kernel forced (RPDE_ANA_SQ=0)
+    for leg in ({}, {"RPDE_ANA_SQ": "0"}):
         with _env(**leg):
             fused = run()
         for name, p, q in zip(("out", "dx", "dWy", "dWx"), fused, plain):
