@@ -22,6 +22,24 @@ if mode == "eval":
     with torch.no_grad():
         for _ in range(2):
             ff(x, residual=res)
+elif mode == "bwd":
+    xg = x.requires_grad_(True)
+    g = torch.randn_like(x)
+    for _ in range(2):
+        ff(xg, residual=res).backward(g)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * (3 * 64))()
+    lib.rpde_debug_ffb_stamps.argtypes = [C.c_void_p]
+    _lib.check(lib.rpde_debug_ffb_stamps(buf), "stamps")
+    t = np.array(buf, dtype=np.uint64).reshape(3, 8, 8).astype(np.int64)
+    names = ["top", "A passed", "B passed", "C passed", "d2 landed", "du2 done", "D passed", "gemm2 + d1 landed"]
+    for wi, wn in enumerate(("wave 0", "wave 3", "wave 6")):
+        print(mode, wn)
+        for ti in range(4):
+            row = t[wi, ti]
+            print("   tile", ti, " ".join(f"{names[i]}:+{int(row[i] - row[0])}" for i in range(1, 8)),
+                  f" | tile period {int(t[wi, ti + 1, 0] - row[0])}")
+    sys.exit(0)
 else:
     xg = x.requires_grad_(True)
     for _ in range(2):

@@ -32,8 +32,11 @@ namespace rpde {
 // debug build: lane 0 of waves 0, 3 and 6 of workgroup 100 records s_memtime around the phases of its first tiles
 __device__ unsigned long long g_ffstamps[3 * 64];
 #define FFSTAMP(i) do { if (stamp_on && stamp_t < 8) g_ffstamps[stamp_w * 64 + stamp_t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_fbstamps[3 * 64];      // the same for the backward chain kernel
+#define FBSTAMP(i) do { if (stamp_on && stamp_t >= 0 && stamp_t < 8) g_fbstamps[stamp_w * 64 + stamp_t * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FFSTAMP(i) do { } while (0)
+#define FBSTAMP(i) do { } while (0)
 #endif
 
 constexpr int FF_WAVES = 8;
@@ -591,10 +594,8 @@ constexpr int FB_W3L = FB_DUBUF + 32768;           // [8 wave][4 frag][1 KB]: lo
 constexpr int FB_D2 = FB_W3L + 32768;              // [8 wave][4 pieces][1 KB]: d2 of the wave's slice, next tile (LDS-DMA) = 32 KB
 constexpr int FB_D1 = FB_D2 + 32768;               // the same for d1                                              = 32 KB
 constexpr int FB_VEC = FB_D1 + 32768;              // gamma[64] beta[64]
-constexpr int FB_ACC = FB_VEC + 512;               // db1[256] db2[256] db3[2][64] dgamma[2][64] dbeta[2][64] = 3584 B
-constexpr int FB_STAT1 = FB_ACC + 3584;            // [2 blk][4 tile][16 points][mean, M2]                    = 1 KB
-constexpr int FB_STAT2 = FB_STAT1 + 1024;          // [2 blk][4 tile][16 points][s1, s2, amax, -]             = 2 KB
-constexpr int FB_INFO = FB_STAT2 + 2048;           // [2 blk][16 points] bound of |dz3|
+constexpr int FB_ACC = FB_VEC + 512;               // db1[256] db2[256] | db3, dgamma, dbeta: [3][8 wave][64]         = 8 KB
+constexpr int FB_INFO = FB_ACC + 8192;             // [2 blk][16 points] bound of |dz3|
 constexpr int FB_LDS = FB_INFO + 128;
 
 // sum over the 16 lanes of a row (one point block), valid in lane 15 of the row
@@ -603,6 +604,50 @@ __device__ __forceinline__ float row_sum15(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));
+  return v;
+}
+
+// LDS reads / global loads the compiler does not see as such.  An ordinary read of an LDS-DMA landing area makes it wait
+// for vmcnt(0) -- stores included, and again after every store in between -- and an ordinary load that is one tile in
+// flight is answered with vmcnt(0) at its use, i.e. with a wait for the DMA issued just before.  Results pass through
+// the wait statements as tied operands (what orders their uses behind the wait); ONE statement per wait, and the
+// in-flight registers are followed through the ISA by tests/test_isa_pending_loads_cpu.py.
+__device__ __forceinline__ f32x4v fb_lds_read_b128(unsigned addr) {
+  f32x4v r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+__device__ __forceinline__ void fb_lds_wait2(f32x4v& a, f32x4v& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)::"memory");
+}
+__device__ __forceinline__ void fb_lds_write_b128(unsigned addr, f32x4v v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fb_lds_write_b64(unsigned addr, uint2 v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fb_lds_write_b32(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4v fb_gload(const float* p) {
+  f32x4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// sum / maximum over the 16 lanes of a row, in every lane (quad butterflies, then the two mirrors)
+template <bool MAX>
+__device__ __forceinline__ float row_all16(float v) {
+#define RPDE_ROW_STEP(CTRL)                                                                               \
+  {                                                                                                       \
+    const float o_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); \
+    v = MAX ? fmaxf(v, o_) : v + o_;                                                                      \
+  }
+  RPDE_ROW_STEP(0xB1)      // quad_perm [1,0,3,2]
+  RPDE_ROW_STEP(0x4E)      // quad_perm [2,3,0,1]
+  RPDE_ROW_STEP(0x141)     // row_half_mirror
+  RPDE_ROW_STEP(0x140)     // row_mirror
+#undef RPDE_ROW_STEP
   return v;
 }
 
@@ -628,27 +673,27 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
     float* vecw = reinterpret_cast<float*>(smem + FB_VEC);
     float* accw = reinterpret_cast<float*>(smem + FB_ACC);
     for (int i = tid; i < 128; i += 64 * FF_WAVES) vecw[i] = i < 64 ? (A.gamma ? A.gamma[i] : 1.f) : (A.beta ? A.beta[i - 64] : 0.f);
-    for (int i = tid; i < 896; i += 64 * FF_WAVES) accw[i] = 0.f;
+    for (int i = tid; i < 2048; i += 64 * FF_WAVES) accw[i] = 0.f;
   }
   const float* const vec = reinterpret_cast<const float*>(smem + FB_VEC);
   float* const acc_db1 = reinterpret_cast<float*>(smem + FB_ACC);
   float* const acc_db2 = acc_db1 + 256;
-  float* const acc_db3 = acc_db1 + 512;        // [2][64]
-  float* const acc_dg = acc_db1 + 640;         // [2][64]
-  float* const acc_dbt = acc_db1 + 768;        // [2][64]
-  float* const stat1 = reinterpret_cast<float*>(smem + FB_STAT1);
-  float* const stat2 = reinterpret_cast<float*>(smem + FB_STAT2);
+  float* const acc_db3 = acc_db1 + 512;        // [8 wave][64]
+  float* const acc_dg = acc_db1 + 1024;        // [8 wave][64]
+  float* const acc_dbt = acc_db1 + 1536;       // [8 wave][64]
   float* const info = reinterpret_cast<float*>(smem + FB_INFO);
   const float winv1 = A.consts[0], winv2 = A.consts[1], winv3 = A.consts[2], c3t = A.consts[3], c2t = A.consts[4];
-  const int t3 = w & 3, b3 = w >> 2;           // role in the pointwise phases: 16 features x 16 points
-  const int feat = 16 * t3 + 4 * g;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  // role in the last-layer adjoint: one POINT per 16-lane row (point 4 w + q of the tile), lane li takes features
+  // 4 li .. 4 li + 3 -- the LayerNorm statistics are sums over a row (DPP), no exchange between waves
+  const int q3 = l >> 4, feat = 4 * li;
 
   // this wave's float4 of g and of z3 per lane, fetched one tile ahead into registers
-  float4 g4n = make_float4(0.f, 0.f, 0.f, 0.f), z4n = g4n;
+  f32x4v g4n = {0.f, 0.f, 0.f, 0.f}, z4n = g4n;
   auto in_issue = [&](int tile) {
-    const long p = min((long)tile * 32 + 16 * b3 + li, A.P - 1);
-    g4n = *reinterpret_cast<const float4*>(A.g + p * 64 + feat);
-    z4n = *reinterpret_cast<const float4*>(A.z3 + p * 64 + feat);
+    const long p = min((long)tile * 32 + 4 * w + q3, A.P - 1);
+    g4n = fb_gload(A.g + p * 64 + feat);
+    z4n = fb_gload(A.z3 + p * 64 + feat);
   };
   // d2 / d1 of this wave's hidden slice for one tile: four 1 KB pieces (block, row tile), each lane's float4 at [piece][lane]
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -662,6 +707,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
         __builtin_amdgcn_global_load_lds((glb_ptr)(q), (lds_ptr)(smem + area + (w * 4 + blk * 2 + t) * 1024), 16, 0, 0);
       }
   };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the weights: from here on the queue is counted by hand)
   if ((int)blockIdx.x < A.ntiles) {
     in_issue(blockIdx.x);
     d_issue(A.d2, FB_D2, blockIdx.x);
@@ -670,45 +716,43 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
   lds_barrier();                               // vectors and zeroed accumulators are in LDS
 
   bool first = true;
+#ifdef RPDE_STAMPS
+  const bool stamp_on = blockIdx.x == 100 && l == 0 && (w == 0 || w == 3 || w == 6);
+  const int stamp_w = w == 0 ? 0 : (w == 3 ? 1 : 2);
+  int stamp_t = -4;
+#endif
   for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    FBSTAMP(0);
     const int next_tile = tile + gridDim.x;
     const bool has_next = next_tile < A.ntiles;
     const long p0 = (long)tile * 32;
-    const long pt3 = p0 + 16 * b3 + li;
+    const int ptl = 4 * w + q3;                    // this row's point of the tile
+    const long pt3 = p0 + ptl;
     const bool live3 = pt3 < A.P;
     const long off3 = min(pt3, A.P - 1) * 64 + feat;
-    // ---- last-layer adjoint: dropout, LayerNorm, post-activation ----
-    const float4 g4 = g4n, z4 = z4n;
+    // ---- last-layer adjoint: dropout, LayerNorm, post-activation (per row: no barrier, no exchange) ----
+    // g / z3 of this tile were requested a tile ago; behind them, in program order, are the four du1 stores of that
+    // tile (a tile that has a successor is full: all four are issued) and the four pieces of the d1 DMA -- first tile:
+    // the eight DMA pieces of the prologue
+    asm volatile("s_waitcnt vmcnt(8) ; landed %0 %1" : "+v"(g4n), "+v"(z4n)::"memory");
+    const f32x4v g4 = g4n, z4 = z4n;
     float s4[4] = {1.f, 1.f, 1.f, 1.f};
     if (A.drop2.on()) drop_scale4(A.drop2, (uint64_t)(pt3 * 64 + feat), s4);
     const float tz[4] = {z4.x * s4[0], z4.y * s4[1], z4.z * s4[2], z4.w * s4[3]};
     float gy[4] = {g4.x, g4.y, g4.z, g4.w};
     if (!live3) { gy[0] = gy[1] = gy[2] = gy[3] = 0.f; }
     float dz[4], dzb;
+    float dgm[4] = {0.f, 0.f, 0.f, 0.f}, dbt[4] = {0.f, 0.f, 0.f, 0.f};
     if (A.layer_norm) {
-      float sum = (tz[0] + tz[1]) + (tz[2] + tz[3]);
-      sum += lane_xor16(sum);
-      sum += lane_xor32(sum);
-      const float mw = sum * (1.f / 16.f);
-      float m2 = (tz[0] - mw) * (tz[0] - mw) + (tz[1] - mw) * (tz[1] - mw) + (tz[2] - mw) * (tz[2] - mw) + (tz[3] - mw) * (tz[3] - mw);
-      m2 += lane_xor16(m2);
-      m2 += lane_xor32(m2);
-      if (g == 0) *reinterpret_cast<float2*>(stat1 + ((b3 * 4 + t3) * 16 + li) * 2) = make_float2(mw, m2);
-      lds_barrier();                                                                  // A
-      float mws[4], m2s = 0.f, mean = 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float2 s2 = *reinterpret_cast<const float2*>(stat1 + ((b3 * 4 + t) * 16 + li) * 2);
-        mws[t] = s2.x; m2s += s2.y; mean += s2.x;
-      }
-      mean *= 0.25f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) m2s += 16.f * (mws[t] - mean) * (mws[t] - mean);
-      const float rstd = rsqrtf(m2s * (1.f / 64.f) + A.eps);
-      const float4 gm = *reinterpret_cast<const float4*>(vec + feat);
-      const float4 bt = *reinterpret_cast<const float4*>(vec + 64 + feat);
+      const float mean = row_all16<false>((tz[0] + tz[1]) + (tz[2] + tz[3])) * (1.f / 64.f);
+      const float m2 = row_all16<false>((tz[0] - mean) * (tz[0] - mean) + (tz[1] - mean) * (tz[1] - mean) +
+                                        (tz[2] - mean) * (tz[2] - mean) + (tz[3] - mean) * (tz[3] - mean));
+      const float rstd = rsqrtf(m2 * (1.f / 64.f) + A.eps);
+      f32x4v gm = fb_lds_read_b128(lds0 + FB_VEC + feat * 4);
+      f32x4v bt = fb_lds_read_b128(lds0 + FB_VEC + 256 + feat * 4);
+      fb_lds_wait2(gm, bt);
       const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
-      float xh[4], dxh[4], s1 = 0.f, s2 = 0.f, am = 0.f, dgm[4], dbt[4];
+      float xh[4], dxh[4], s1 = 0.f, s2 = 0.f, am = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         xh[k] = (tz[k] - mean) * rstd;
@@ -721,65 +765,63 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
         s2 += dxh[k] * xh[k];
         am = fmaxf(am, fabsf(dxh[k]));
       }
-      s1 += lane_xor16(s1); s1 += lane_xor32(s1);
-      s2 += lane_xor16(s2); s2 += lane_xor32(s2);
-      am = fmaxf(am, lane_xor16(am)); am = fmaxf(am, lane_xor32(am));
-      if (g == 0) *reinterpret_cast<float4*>(stat2 + ((b3 * 4 + t3) * 16 + li) * 4) = make_float4(s1, s2, am, rstd);
-      // gamma / beta gradients: sum over the 16 points of the block, one writer per (block, feature)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { dgm[k] = row_sum15(dgm[k]); dbt[k] = row_sum15(dbt[k]); }
-      if (li == 15) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { acc_dg[b3 * 64 + feat + k] += dgm[k]; acc_dbt[b3 * 64 + feat + k] += dbt[k]; }
-      }
-      lds_barrier();                                                                  // B
-      float S1 = 0.f, S2 = 0.f, AM = 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float4 q = *reinterpret_cast<const float4*>(stat2 + ((b3 * 4 + t) * 16 + li) * 4);
-        S1 += q.x; S2 += q.y; AM = fmaxf(AM, q.z);
-      }
-      S1 *= (1.f / 64.f); S2 *= (1.f / 64.f);
+      const float S1 = row_all16<false>(s1) * (1.f / 64.f), S2 = row_all16<false>(s2) * (1.f / 64.f);
+      const float AM = row_all16<true>(am);
 #pragma unroll
       for (int k = 0; k < 4; ++k) dz[k] = rstd * (dxh[k] - S1 - xh[k] * S2) * s4[k];
-      // bound of |dz3| over the block (identical in the four waves of the block): |xhat| <= sqrt(63) < 8
-      // bound of this POINT's |dz3| (identical in the four waves that share the point): |xhat| <= sqrt(63) < 8
+      // bound of this POINT's |dz3|: |xhat| <= sqrt(63) < 8
       dzb = rstd * (AM + fabsf(S1) + 8.f * fabsf(S2)) * A.drop2.scale;
     } else {
       float am = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { dz[k] = gy[k] * dact_f(A.post_act, tz[k]) * s4[k]; am = fmaxf(am, fabsf(dz[k])); }
-      am = fmaxf(am, lane_xor16(am)); am = fmaxf(am, lane_xor32(am));
-      if (g == 0) stat2[((b3 * 4 + t3) * 16 + li) * 4] = am;
-      lds_barrier();                                                                  // B (A is not needed)
-      float AM = 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) AM = fmaxf(AM, stat2[((b3 * 4 + t) * 16 + li) * 4]);
-      dzb = AM;
+      dzb = row_all16<true>(am);
     }
     if (live3) *reinterpret_cast<float4*>(A.dz3 + off3) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+    // bias / gamma / beta gradients: sum over the wave's four points (rows), one writer per (wave, feature); the
+    // eight waves' sums are combined in fixed order at the end
     {
       float b[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) b[k] = row_sum15(live3 ? dz[k] : 0.f);
-      if (li == 15) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc_db3[b3 * 64 + feat + k] += b[k];
+      for (int k = 0; k < 4; ++k) {
+        b[k] = live3 ? dz[k] : 0.f;
+        b[k] += lane_xor16(b[k]); b[k] += lane_xor32(b[k]);
+        if (A.layer_norm) {
+          dgm[k] += lane_xor16(dgm[k]); dgm[k] += lane_xor32(dgm[k]);
+          dbt[k] += lane_xor16(dbt[k]); dbt[k] += lane_xor32(dbt[k]);
+        }
+      }
+      if (q3 == 0) {
+        // (asm: an ordinary access here is preceded by vmcnt(0) -- the compiler cannot tell these addresses from the
+        //  DMA's landing areas -- i.e. by a wait for the d1 pieces requested a moment ago)
+        const unsigned a0 = lds0 + FB_ACC + (512 + w * 64 + feat) * 4;
+        f32x4v v3 = fb_lds_read_b128(a0), vg = fb_lds_read_b128(a0 + 2048), vb = fb_lds_read_b128(a0 + 4096);
+        fb_lds_wait2(v3, vg);
+        fb_lds_wait2(vb, vb);
+        v3.x += b[0]; v3.y += b[1]; v3.z += b[2]; v3.w += b[3];
+        fb_lds_write_b128(a0, v3);
+        if (A.layer_norm) {
+          vg.x += dgm[0]; vg.y += dgm[1]; vg.z += dgm[2]; vg.w += dgm[3];
+          vb.x += dbt[0]; vb.y += dbt[1]; vb.z += dbt[2]; vb.w += dbt[3];
+          fb_lds_write_b128(a0 + 2048, vg);
+          fb_lds_write_b128(a0 + 4096, vb);
+        }
       }
     }
-    // dz3 -> B fragments: (block b3, half ks = t3 >> 1); this wave fills the 8-byte half (t3 & 1) of every lane's
-    // 16 bytes.  One scale per point, from the bound dzb that the four waves sharing the point computed identically.
+    // dz3 -> B fragments (one scale per point, its bound dzb): features 4 li .. 4 li + 3 of point ptl are reduction slots
+    // 4 (li >> 2 & 1) .. + 3 of lane group li & 3 in the fragment (block ptl >> 4, half ks = li >> 3), point column ptl & 15
     {
       float sdz, sdzi;
       h2_scale(dzb, 0, sdz, sdzi);
       uint2 hi, lo;
       h2_split4(dz[0] * sdz, dz[1] * sdz, dz[2] * sdz, dz[3] * sdz, hi, lo);
-      char* dst = smem + FB_DZBUF + ((b3 * 2 + (t3 >> 1)) * 2) * 1024 + l * 16 + (t3 & 1) * 8;
-      *reinterpret_cast<uint2*>(dst) = hi;
-      *reinterpret_cast<uint2*>(dst + 1024) = lo;
-      if (t3 == 0 && g == 0) info[b3 * 16 + li] = dzb;
+      const unsigned dst = lds0 + FB_DZBUF + (((ptl >> 4) * 2 + (li >> 3)) * 2) * 1024 + ((li & 3) * 16 + (ptl & 15)) * 16 + ((li >> 2) & 1) * 8;
+      fb_lds_write_b64(dst, hi);
+      fb_lds_write_b64(dst + 1024, lo);
+      if (li == 0) fb_lds_write_b32(lds0 + FB_INFO + ptl * 4, dzb);
     }
     lds_barrier();                                                                    // C: dz3 fragments + bounds in LDS
+    FBSTAMP(3);
 
     // per point: scale of dz3 (its bound), of du2 and du1 (bounds derived from it); recomputed at each use
     auto bscales = [&](int blk, float& inv_a, float& s_du2, float& inv_b, float& s_du1, float& inv_c) {
@@ -800,9 +842,14 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
     // younger than that DMA are, in program order, the next tile's g / z3 loads (2), the du1 stores (4), the d1 DMA
     // (4) and this tile's dz3 store: 10 or 11 (first tile: only the d1 DMA and the dz3 store)
     if (first) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    FBSTAMP(4);
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
+      f32x4v dq[2];                                // the wave's two pieces [t] of d2 for this block
+      dq[0] = fb_lds_read_b128(lds0 + FB_D2 + (w * 4 + blk * 2) * 1024 + l * 16);
+      dq[1] = fb_lds_read_b128(lds0 + FB_D2 + (w * 4 + blk * 2 + 1) * 1024 + l * 16);
+      fb_lds_wait2(dq[0], dq[1]);
       const char* zb = smem + FB_DZBUF + (blk * 2) * 2048 + l * 16;
       const f16x8 zh0 = *reinterpret_cast<const f16x8*>(zb), zl0 = *reinterpret_cast<const f16x8*>(zb + 1024);
       const f16x8 zh1 = *reinterpret_cast<const f16x8*>(zb + 2048), zl1 = *reinterpret_cast<const f16x8*>(zb + 3072);
@@ -818,7 +865,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
         acc = h2_mfma32(w3h[t][0], w3l0, zh0, zl0, acc);
         acc = h2_mfma32(w3h[t][1], w3l1, zh1, zl1, acc);
         const int hid = 16 * (2 * w + t) + 4 * g;
-        float4 d = *reinterpret_cast<const float4*>(smem + FB_D2 + (w * 4 + blk * 2 + t) * 1024 + l * 16);
+        float4 d = make_float4(dq[t].x, dq[t].y, dq[t].z, dq[t].w);
         if (RECOMP) d = ff_dact4(d, A.drop1, (uint64_t)(pt * 256 + hid));
         const float u[4] = {acc[0] * inv_a * d.x, acc[1] * inv_a * d.y, acc[2] * inv_a * d.z, acc[3] * inv_a * d.w};
         if (pt < A.P) {
@@ -829,7 +876,17 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[4 * t + r] = u[r] * s_du2;
       }
-      ff_put_frag(smem + FB_DUBUF + ((blk * 8 + w) * 2) * 1024 + l * 16, hv);
+      {                                            // (ff_put_frag through asm writes: see fb_lds_read_b128)
+        uint2 h0, l0, h1, l1;
+        h2_split4(hv[0], hv[1], hv[2], hv[3], h0, l0);
+        h2_split4(hv[4], hv[5], hv[6], hv[7], h1, l1);
+        const unsigned dst = lds0 + FB_DUBUF + ((blk * 8 + w) * 2) * 1024 + l * 16;
+        f32x4v ph, pl;
+        ph.x = __uint_as_float(h0.x); ph.y = __uint_as_float(h0.y); ph.z = __uint_as_float(h1.x); ph.w = __uint_as_float(h1.y);
+        pl.x = __uint_as_float(l0.x); pl.y = __uint_as_float(l0.y); pl.z = __uint_as_float(l1.x); pl.w = __uint_as_float(l1.y);
+        fb_lds_write_b128(dst, ph);
+        fb_lds_write_b128(dst + 1024, pl);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) bsum[i] = row_sum15(bsum[i]);
@@ -842,7 +899,9 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       d_issue(A.d2, FB_D2, next_tile);
       in_issue(next_tile);
     }
+    FBSTAMP(5);
     lds_barrier();                                                                    // D: du2 slices in LDS
+    FBSTAMP(6);
 
     // ---- du1 = (W2^T du2) * d1 ----
 #pragma unroll
@@ -864,15 +923,20 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       // a next tile -- its d2 DMA (4) and g / z3 loads (2): 11; in the last tile only the stores of live points are
       // certain (at least two du2 stores: block 0 has a live point)
       if (has_next) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      FBSTAMP(7);
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
+        f32x4v dq[2];
+        dq[0] = fb_lds_read_b128(lds0 + FB_D1 + (w * 4 + blk * 2) * 1024 + l * 16);
+        dq[1] = fb_lds_read_b128(lds0 + FB_D1 + (w * 4 + blk * 2 + 1) * 1024 + l * 16);
+        fb_lds_wait2(dq[0], dq[1]);
         const long pt = p0 + 16 * blk + li;
         float q0, q1, inv_b, s_du1, q2;
         bscales(blk, q0, q1, inv_b, s_du1, q2);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int hid = 16 * (2 * w + t) + 4 * g;
-          float4 d = *reinterpret_cast<const float4*>(smem + FB_D1 + (w * 4 + blk * 2 + t) * 1024 + l * 16);
+          float4 d = make_float4(dq[t].x, dq[t].y, dq[t].z, dq[t].w);
           if (RECOMP) d = ff_dact4(d, A.drop0, (uint64_t)(pt * 256 + hid));
           const float u[4] = {acc[blk][t][0] * inv_b * d.x, acc[blk][t][1] * inv_b * d.y,
                               acc[blk][t][2] * inv_b * d.z, acc[blk][t][3] * inv_b * d.w};
@@ -895,6 +959,9 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
       for (int i = 0; i < 8; ++i) acc_db1[16 * (2 * w + (i >> 2)) + 4 * g + (i & 3)] += bsum[i];
     }
     first = false;
+#ifdef RPDE_STAMPS
+    ++stamp_t;
+#endif
   }
   // ---- per-workgroup sums out ----
   lds_barrier();
@@ -903,9 +970,12 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
     for (int i = tid; i < FFB_PART; i += 64 * FF_WAVES) {
       float v;
       if (i < 512) v = acc_db1[i];                                   // db1, db2
-      else if (i < 576) v = acc_db3[i - 512] + acc_db3[64 + i - 512];
-      else if (i < 640) v = acc_dg[i - 576] + acc_dg[64 + i - 576];
-      else v = acc_dbt[i - 640] + acc_dbt[64 + i - 640];
+      else {                                                         // db3 | dgamma | dbeta: the eight waves' sums, in order
+        const float* a8 = acc_db3 + ((i - 512) >> 6) * 512 + ((i - 512) & 63);
+        v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FF_WAVES; ++ww) v += a8[ww * 64];
+      }
       part[i] = v;
     }
   }
@@ -1011,6 +1081,11 @@ int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, int re
 }  // namespace rpde
 
 #ifdef RPDE_STAMPS
+extern "C" int rpde_debug_ffb_stamps(unsigned long long* host_out) {
+  RPDE_HIP(hipDeviceSynchronize());
+  RPDE_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rpde::g_fbstamps), sizeof(unsigned long long) * 3 * 64));
+  return RPDE_OK;
+}
 extern "C" int rpde_debug_ff_stamps(unsigned long long* host_out) {
   RPDE_HIP(hipDeviceSynchronize());
   RPDE_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(rpde::g_ffstamps), sizeof(unsigned long long) * 3 * 64));
