@@ -246,6 +246,8 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
         for (int r = 0; r < 4; ++r)
           if (p0 + r < P.npts) gq[(long)r * P.N] = tot[r];
       }
+      // (tried: the data-gradient stores behind convert / issue, so that the loader's vmcnt(0) does not wait for their
+      //  acknowledgement: 772 vs 684 us in a run where the other two instances were 3-5 % slower than their record -- worse)
       if (s + 1 < s1) {
         convert(cur ^ 1);                    // waits for the loads of step s + 1
         issue(s + 2);
