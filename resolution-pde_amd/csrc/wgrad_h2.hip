@@ -24,6 +24,7 @@
 // are scaled by it, and a consumer wave whose panels' exponents moved rescales its accumulators once (a wave-uniform
 // branch that is taken a handful of times per launch).  No pass over the data to find a global maximum, no
 // per-step accumulator arithmetic, robust to isolated huge points.
+#include <stdio.h>
 #include "h2.h"
 #include "pointwise.h"
 #include "wgrad_h2.h"
@@ -54,6 +55,7 @@ struct WgP {
   int M, N, nchunk;
   const float* w;      // DG only: the layer's weight [M, N]
   float* gx;           // DG only: gx[P, N] = gy[P, M] . w
+  int early;           // bit w: wave w converts the next step's panel BEFORE this step's products
 };
 
 // PA / PB: 64-channel panels of the A block / of B; waves WM x WN, each TM x TN tiles of 16 x 16; ACT: B = gelu(b).
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
   // this wave's output tile of gx: points 16 (wave & 1) .., input channels 16 (wave >> 1) ..
   const int dg_mt = wave & 1, dg_nt = wave >> 1;
 
+  const bool early_convert = (P.early >> __builtin_amdgcn_readfirstlane(wave)) & 1;
   if (s0 < s1) {
     issue(s0);
     convert(0);
@@ -195,6 +198,14 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
     for (long s = s0; s < s1; ++s) {
       const int cur = (int)(s - s0) & 1;
       const char* const stage = smem + cur * STAGE;
+      // The loader's conversion of the NEXT step's panels (vector work, into the other stage) stands in front of this
+      // step's products (matrix work) for waves 4-7 and behind them for waves 0-3 -- wave w and w + 4 share a SIMD, so
+      // one of them converts while the other feeds the matrix pipe; with all eight in the same order the two kinds of
+      // work simply added up (the accumulator chains of a wave are independent: one wave fills the pipe).
+      if (early_convert && s + 1 < s1) {
+        convert(cur ^ 1);                    // waits for the loads of step s + 1
+        issue(s + 2);
+      }
       const int eb = __builtin_amdgcn_readfirstlane(einfo[cur][pb]);
 #pragma unroll
       for (int k = 0; k < NPA; ++k) {
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
       }
       // (tried: the data-gradient stores behind convert / issue, so that the loader's vmcnt(0) does not wait for their
       //  acknowledgement: 772 vs 684 us in a run where the other two instances were 3-5 % slower than their record -- worse)
-      if (s + 1 < s1) {
+      if (!early_convert && s + 1 < s1) {
         convert(cur ^ 1);                    // waits for the loads of step s + 1
         issue(s + 2);
       }
@@ -277,6 +288,17 @@ bool wgrad_h2_ok(long P, int out_f, int in_f) {
 
 static int wg_chunks(int, int) { return WG_BLOCKS; }
 
+// Which waves convert early (k_wgrad_h2), measured same-box with rocprofv3 over the masks (RPDE_WG_EARLY=<hex 256x256>,
+// <hex 64x256>,<hex 256x64> overrides, for such sweeps): 256x256 (eight loaders) waves 4-7 early 820-834 us, all in one
+// order 878-898, waves 0-3 early 942 (the lower wave of a SIMD pair seems to win the matrix pipe: it should be the one
+// that goes there first); 64x256 (loaders 0-4) waves 1-3 early 490 vs 513-518 us; 256x64 with the data gradient: no
+// mask beat the common order (753-762 us), most lost.
+static int wg_early_mask(int out_f, int in_f) {
+  int m[3] = {0xF0, 0x0E, 0x00};
+  if (const char* e = getenv("RPDE_WG_EARLY")) sscanf(e, "%x,%x,%x", &m[0], &m[1], &m[2]);
+  return out_f == 256 && in_f == 256 ? m[0] : (out_f == 64 ? m[1] : m[2]);
+}
+
 size_t wgrad_h2_slab_floats(long P, int out_f, int in_f) {
   return wgrad_h2_ok(P, out_f, in_f) ? (size_t)wg_chunks(out_f, in_f) * out_f * in_f : 0;
 }
@@ -295,6 +317,7 @@ int wgrad_h2_dgrad(const float* gy, const float* h, const float* w, float* gw, f
   RPDE_CHECK_ARG(wgrad_h2_dgrad_ok(P, out_f, in_f) && slabs && w && gx, "wgrad_h2_dgrad: unsupported shape");
   WgP p;
   p.a = gy; p.b = h; p.slabs = slabs; p.npts = P; p.steps = (P + 31) / 32; p.M = out_f; p.N = in_f; p.nchunk = WG_BLOCKS;
+  p.early = wg_early_mask(out_f, in_f);
   p.w = w; p.gx = gx;
   hipLaunchKernelGGL((k_wgrad_h2<4, 1, 4, 2, 4, 2, false, true>), dim3(p.nchunk, 1), dim3(64 * WG_WAVES), 0, st, p);
   RPDE_LAUNCH_CHECK();
@@ -306,6 +329,7 @@ int wgrad_h2(const float* gy, const float* h, float* gw, long P, int in_f, int o
   RPDE_CHECK_ARG(act_b == RPDE_ACT_IDENTITY || act_b == RPDE_ACT_GELU, "wgrad_h2: activation %d", act_b);
   WgP p;
   p.a = gy; p.b = h; p.slabs = slabs; p.npts = P; p.steps = (P + 31) / 32; p.M = out_f; p.N = in_f; p.nchunk = wg_chunks(out_f, in_f);
+  p.early = wg_early_mask(out_f, in_f);
   p.w = nullptr; p.gx = nullptr;
   const bool act = act_b == RPDE_ACT_GELU;
   if (out_f == 256 && in_f == 256) wg_launch<4, 4, 2, 4, 8, 4>(p, 1, act, st);
