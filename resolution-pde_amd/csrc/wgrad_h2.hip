@@ -58,6 +58,20 @@ struct WgP {
   int early;           // bit w: wave w converts the next step's panel BEFORE this step's products
 };
 
+// 4 x 4 transpose inside every quad of lanes: afterwards register c of lane p (p = lane & 3) holds what register p of
+// lane c held (two butterfly stages on DPP quad permutes; the synthesis kernel's output uses the same)
+template <int CTRL>
+__device__ __forceinline__ float wg_quad_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void wg_quad_transpose(float& v0, float& v1, float& v2, float& v3) {
+  const bool b0 = threadIdx.x & 1, b1 = threadIdx.x & 2;
+  { const float a = wg_quad_dpp<0xB1>(v0), c = wg_quad_dpp<0xB1>(v1); v1 = b0 ? v1 : a; v0 = b0 ? c : v0; }   // quad_perm [1,0,3,2]
+  { const float a = wg_quad_dpp<0xB1>(v2), c = wg_quad_dpp<0xB1>(v3); v3 = b0 ? v3 : a; v2 = b0 ? c : v2; }
+  { const float a = wg_quad_dpp<0x4E>(v0), c = wg_quad_dpp<0x4E>(v2); v2 = b1 ? v2 : a; v0 = b1 ? c : v0; }   // quad_perm [2,3,0,1]
+  { const float a = wg_quad_dpp<0x4E>(v1), c = wg_quad_dpp<0x4E>(v3); v3 = b1 ? v3 : a; v1 = b1 ? c : v1; }
+}
+
 // PA / PB: 64-channel panels of the A block / of B; waves WM x WN, each TM x TN tiles of 16 x 16; ACT: B = gelu(b).
 // DG: the layer's data gradient rides along -- gx[p, :] = gy[p, :] . W for the 32 points of every step, from the gy
 // panels that are in LDS anyway (plain 16-byte reads: here the reduction index is the channel), so gy is read from
@@ -251,11 +265,12 @@ __global__ __launch_bounds__(64 * WG_WAVES, 2) void k_wgrad_h2(const WgP P) {
           const float fk = __uint_as_float((unsigned)(ek - 14) << 23) * w_inv;
           tot += part * fk;
         }
-        const long p0 = s * 32 + 16 * dg_mt + 4 * g;
-        float* __restrict__ gq = P.gx + p0 * P.N + 16 * dg_nt + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (p0 + r < P.npts) gq[(long)r * P.N] = tot[r];
+        // lane (g, li) holds points 4 g + r (r = 0..3) of channel li; a 4 x 4 transpose inside every quad of lanes turns
+        // that into four consecutive channels of ONE point per lane: one 16-byte store instead of four 4-byte ones
+        float t0 = tot[0], t1 = tot[1], t2 = tot[2], t3 = tot[3];
+        wg_quad_transpose(t0, t1, t2, t3);
+        const long pq = s * 32 + 16 * dg_mt + 4 * g + (li & 3);
+        if (pq < P.npts) *reinterpret_cast<float4*>(P.gx + pq * P.N + 16 * dg_nt + 4 * (li >> 2)) = make_float4(t0, t1, t2, t3);
       }
       // (tried: the data-gradient stores behind convert / issue, so that the loader's vmcnt(0) does not wait for their
       //  acknowledgement: 772 vs 684 us in a run where the other two instances were 3-5 % slower than their record -- worse)
