@@ -180,7 +180,8 @@ static bool fused_mix_on() {
 }
 
 // slabs of lines for the h2 weight gradient of the mix: enough workgroups to fill the chip (keff x S x 2), at least four
-// 32-line tiles each
+// 32-line tiles each (more slabs do not help: S = 20 / 24 / 32 / 48 gave 108 / 105 / 110 / 109 us against 102 at 12,
+// and the fold grows from 7.6 to 29 us)
 static int mixw_slabs(const Axis& ay, const Axis& ax) {
   const long tiles = (ay.rows < ax.rows ? ay.rows : ax.rows) / 32;
   long S = tiles / 4;
