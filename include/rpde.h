@@ -262,9 +262,10 @@ int rpde_conv1x1_act_fwd(const float* x, const float* w, const float* b, float* 
  * reference models/fno_blocks.py:63-83 with models/spectral_convolution.py:79-98.  The inverse DFT along the last
  * axis, the bypass convolution, bias and activation run as ONE streaming pass over x: the spectral branch is never
  * written.  x [B,Cin,M,N], w1/w2 complex [Cin,Cout,m1,m2] (as float pairs), wc [Cout,Cin], out [B,Cout,M,N].
- * rpde_fnoblock2d_eval_ok: 1 when the shape is covered (Cout <= 32, N % 4 == 0, N divides 1024 or is a multiple of it). */
+ * rpde_fnoblock2d_eval_ok: 1 when the shape is covered (Cout <= 32, N % 4 == 0, N divides 1024 or is a multiple of it, and the
+ * block's weights plus its rows' 2 * ceil4(m2) spectrum entries fit 64 KB of LDS). */
 size_t rpde_fnoblock2d_eval_ws_bytes(int B, int Cin, int Cout, int M, int N, int m1, int m2);
-int rpde_fnoblock2d_eval_ok(int Cin, int Cout, int M, int N);
+int rpde_fnoblock2d_eval_ok(int Cin, int Cout, int M, int N, int m2);
 int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc, float* out,
                              int B, int Cin, int Cout, int M, int N, int m1, int m2, int act_out,
                              void* ws, size_t ws_bytes, void* stream);

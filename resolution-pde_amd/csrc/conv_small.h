@@ -9,7 +9,7 @@ int conv1x1_small(const float* x, const float* w, const float* bias, float* out,
                   int accumulate, int act_out, hipStream_t st);
 // the same pass with the last stage of a channels-first spectral convolution folded in (evaluation-mode FNO block):
 // t [B,Cout,M,R2] row spectra, fs_t [R2,N] transposed synthesis table
-bool conv1x1_syn_ok(const float* x, const float* out, int Cin, int Cout, int M, int N);
+bool conv1x1_syn_ok(const float* x, const float* out, int Cin, int Cout, int M, int N, int R2);
 int conv1x1_syn(const float* x, const float* w, const float* bias, const float* t, const float* fs_t, float* out, int B, int Cin,
                 int Cout, int M, int N, int R2, int act_out, hipStream_t st);
 // the same on the matrix pipe (conv_syn_h2.hip): N in {64,128,256,512}, Cin = 32, Cout <= 32, R2 a multiple of 8

@@ -130,8 +130,17 @@ int conv1x1_small(const float* x, const float* w, const float* bias, float* out,
 
 // rows of N points: N a multiple of 4 that divides 1024 or is a multiple of it (a block's 1024 points are whole rows or
 // lie inside one)
-bool conv1x1_syn_ok(const float* x, const float* out, int Cin, int Cout, int M, int N) {
-  return conv1x1_small_ok(x, out, Cin, Cout, (long)M * N) && N % 4 == 0 && (1024 % N == 0 || N % 1024 == 0);
+// and the block's weights + its rows' spectra fit the 64 KB of dynamic LDS a launch gets without opting in to more
+// (narrow grids keep many rows per block: width 32, 12 modes at N = 32 would need 100 KB -- such shapes take the
+// two-step path)
+static size_t conv1x1_syn_lds(int Cin, int Cout, int N, int R2) {
+  const int CO = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : (Cout <= 16 ? 16 : 32));
+  const int rows = N >= 1024 ? 1 : 1024 / N;
+  return sizeof(float) * ((size_t)Cin * CO + (size_t)rows * R2 * CO);
+}
+bool conv1x1_syn_ok(const float* x, const float* out, int Cin, int Cout, int M, int N, int R2) {
+  return conv1x1_small_ok(x, out, Cin, Cout, (long)M * N) && N % 4 == 0 && (1024 % N == 0 || N % 1024 == 0) &&
+         conv1x1_syn_lds(Cin, Cout, N, R2) <= 64 * 1024;
 }
 
 // out[b][o][m][n] = act_out(bias[o] + sum_i W[o][i] x[b][i][m][n] + sum_r fs_t[r][n] t[b][o][m][r])
@@ -140,8 +149,7 @@ int conv1x1_syn(const float* x, const float* w, const float* bias, const float* 
   const long S = (long)M * N;
   const int CO = Cout <= 4 ? 4 : (Cout <= 8 ? 8 : (Cout <= 16 ? 16 : 32));
   const dim3 grid((unsigned)((S / 4 + 255) / 256), B), block(256);
-  const int rows = N >= 1024 ? 1 : 1024 / N;
-  const size_t lds = sizeof(float) * ((size_t)Cin * CO + (size_t)rows * R2 * CO);
+  const size_t lds = conv1x1_syn_lds(Cin, Cout, N, R2);
   ConvSyn Y{t, fs_t, M, N, R2};
   switch (CO) {
     case 4: hipLaunchKernelGGL((k_conv1x1_small<4, true>), grid, block, lds, st, x, w, bias, out, Cin, Cout, S, 0, 0, act_out, Y); break;

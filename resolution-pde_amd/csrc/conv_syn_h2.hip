@@ -22,6 +22,7 @@
 // No workgroup barrier.  A row's slab of x is requested one whole row ahead (two register buffers; the table fragments
 // live in LDS to make room for them).
 #include "conv_small.h"
+#include "cw.h"
 #include "h2.h"
 
 #include <stdlib.h>
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(512) void k_conv_syn_h2(const float* __restrict__ x
     const long b = r / M, m = r % M;
     // this row's 12 pieces are in; the previous row's 8 stores may still be out (a predicated store that no lane takes is
     // not issued at all, so without FULL the count is unknown and the queue is drained)
-    if (first || !FULL) cs_wait_vmcnt<0>(); else cs_wait_vmcnt<8>();
+    // (cw.h: the request is marked behind its last piece; tests/test_isa_counted_waits_cpu.py checks the 8 on the ISA)
+    if (first || !FULL) cs_wait_vmcnt<0>(); else cw_wait<0, 8>();
     first = false;
     // ---- x slab -> scaled f16 pieces in the staging area; spectra -> A fragments ----
     // (asm reads: an ordinary LDS load of a DMA's landing area makes the compiler wait for vmcnt(0), stores included)
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(512) void k_conv_syn_h2(const float* __restrict__ x
     }
     f32x4v (&tb)[2][2] = *reinterpret_cast<f32x4v (*)[2][2]>(&tq[0]);
     issue(r + stride);                                            // next row's pieces in flight under this row's work
+    cw_mark<0>();
     float mx = 0.f, mtv = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(xb[i].x), fabsf(xb[i].y)), fmaxf(fabsf(xb[i].z), fabsf(xb[i].w))));

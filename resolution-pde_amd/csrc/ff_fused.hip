@@ -23,6 +23,7 @@
 // reduction over activations is ever needed.  A bound that is 2^k too large costs k of the ~15 spare bits of the
 // two-piece format, nothing else.
 #include "ff_fused.h"
+#include "cw.h"
 #include "h2.h"
 #include "pointwise.h"
 
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
     lds_barrier();                         // B0: input fragments of this tile (and, first time, W3 / vectors) are in LDS
     FFSTAMP(1);
     const int next_tile = tile + gridDim.x;
-    if (w < 2 && next_tile < A.ntiles) s_issue(next_tile);
+    if (w < 2 && next_tile < A.ntiles) { s_issue(next_tile); cw_mark<0>(); }
     const long p0 = (long)tile * 32;
 
     // per point (= per lane column): scales of x (its maximum), of h1 and h2 (bounds derived from it), recomputed
@@ -420,8 +421,10 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
     if (w < 2 && next_tile < A.ntiles) {
       // the DMA of the next input tile was issued before this tile's stores (16 in mode 1, 8 in mode 2): it is older
       // than the youngest half of them, so a partial wait covers it without waiting for every store to be acknowledged
-      if (MODE == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (MODE == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // (cw.h; the ISA test checks the counts under the assumption stated above: a tile with a successor is full, so
+      //  every lane-predicated store of it has live lanes and is issued)
+      if (MODE == 1) cw_wait<0, 8>();
+      else if (MODE == 2) cw_wait<0, 4>();
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       s_convert(par ^ 1);
     }

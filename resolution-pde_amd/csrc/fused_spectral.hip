@@ -14,6 +14,7 @@
 //              through its private 16 KB of LDS into the layout of the y-axis part (MFMA rows = n), adds and stores.
 //              The field is written once and never read back (the round-1 path wrote it twice and re-read it once).
 #include "fused_spectral.h"
+#include "cw.h"
 #include "h2.h"
 
 #include <stdlib.h>
@@ -62,9 +63,9 @@ __global__ __launch_bounds__(64) void k_h2_table_ana(const float* __restrict__ s
 // (lo*hi, hi*lo, hi*hi) of each real group are laid side by side along the reduction axis: slot t*TG + q holds, on the
 // table side, piece (lo, hi, hi)[t] of group q and on the spectrum side piece (hi, lo, hi)[t]; slot -> fragment
 // slot / 4, lane group slot % 4.  One MFMA on a packed fragment then yields all three terms: R = 40 costs 4 MFMAs and
-// 3 loads per line instead of 6 and 4.  (A 16-deep MFMA for the tail is not an option: mixing
-// v_mfma_f32_16x16x16_f16 and v_mfma_f32_16x16x32_f16 in one dependent chain gave wrong accumulator registers on
-// gfx950 with ROCm 7.2.)
+// 3 loads per line instead of 6 and 4.  (A 16-deep MFMA for the tail is not an option: a v_mfma_f32_16x16x16_f16 directly
+// behind the v_mfma_f32_16x16x32_f16 it accumulates onto reads a partly written accumulator on gfx950 with ROCm 7.2 --
+// h2.h, profiles/r04_mfma_mix.txt.)
 // (h2_np / h2_block_bytes: fused_spectral.h)
 
 // 8 values of group q (rows 32 K32 + 8 q ..) -> the 16-byte pieces of the three slots they occupy
@@ -366,6 +367,7 @@ struct AnaSqP {
   const float* x; const char* timg;
   float* spec_y; float* spec_x; float* amax_y; float* amax_x;
   int B, n, ks, R, ng, rpw;
+  int b1;          // 1: keep the (redundant) barrier in front of the partial-spectrum writes
 };
 
 template <int MT>
@@ -595,7 +597,10 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
     // wave), one pass, two barriers
     char* const land = smem + TAB;                  // STG + RED = 112 KB >= 8 waves x 12 KB
     FSTAMP(0, sq0 + 2);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everyone's chunks are out of the staging areas
+    // (round 3 had a barrier here, from the time the chunks went through the staging areas that are now part of the landing
+    //  zone; since the chunks stay in registers nothing reads or writes the zone between the previous step's last barrier
+    //  and these writes.  RPDE_ANA_B1=1 brings it back for an A/B.)
+    if (P.b1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     FSTAMP(0, sq0 + 3);
     // a lane's four fragments e = 0..3 hold channels 4 li .. 4 li + 3 of its rows: the partials land as
     // [wave][mt][j][lane] float4 over those four channels, so the sum over the waves is a float4 per (row, li) and the
@@ -1029,8 +1034,10 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
   issue_inv(cur);
 #pragma unroll
   for (int i = 0; i < 2 * NF; ++i) issue_piece(cur, 0, i, 0);
+  cw_mark<3>();                 // (tags 3 / 4: the first tile's stages 0 / 1, waited for under `first`; see k_dft_synthesis4_h2)
 #pragma unroll
   for (int i = 0; i < 2 * NF; ++i) issue_piece(cur, 1, i, 1);
+  cw_mark<4>();
   int ring = 0;                 // slot of the current tile's stage 0
   bool first = true;
   const int qd = li >> 2, pl = li & 3;
@@ -1084,12 +1091,20 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
       // is done; younger than the pieces of stage s are the pieces of stage s + 1 (2 NF) and the stores of the y stages
       // in between (NST each); a wait that also covers table / scale pieces issued in between only over-waits
       // (forward: + the stores in between: 4 at the end of every y stage, 4 at the start of every x stage but the first tile's)
+      // (cw.h: the requests of stage s are marked with the tag s % 3 behind their last piece, and the ISA test checks
+      //  these counts on the compiled code)
       constexpr int Q = SKIP ? 0 : 4;
-      if (SKIP && !first && s < 2) wait_vmcnt<63>();                       // (behind the 64 loads / stores of the epilogue)
-      else if (first && s < 5) wait_vmcnt<2 * NF>();
-      else if (s == 0 || s == 1 || s == 6) wait_vmcnt<2 * NF + 2 * Q>();
-      else if (s <= 5) wait_vmcnt<2 * NF + Q>();
-      else { if (has_next) wait_vmcnt<2 * NF + 2 * Q>(); else wait_vmcnt<2 * Q>(); }
+      const int T = s % 3;
+      // (every stage requests its pieces, the last tile's stages 6 / 7 a harmless re-read: no count depends on has_next.
+      //  The forward instances' counts for stages 2 .. 5 still depend on `first` through the stores at the start of the x
+      //  stages, which the path-insensitive ISA check cannot follow: it covers the SKIP instances -- the ones the default
+      //  dispatch uses; the forward runs k_dft_synthesis4_h2.)
+      if (SKIP && !first && s < 2) cw_wait_t<63>(T);                       // (behind the 64 loads / stores of the epilogue)
+      else if (first && s < 2) { if (s == 0) cw_wait<3, 2 * NF>(); else cw_wait<4, 2 * NF>(); }
+      else if (first && s < 5) cw_wait_t<2 * NF>(T);
+      else if (s == 0 || s == 1 || s == 6) cw_wait_t<2 * NF + 2 * Q>(T);
+      else if (s <= 5) cw_wait_t<2 * NF + Q>(T);
+      else cw_wait_t<2 * NF + 2 * Q>(T);
       FSTAMP(1, 1 + 3 * s);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's have; everyone is done with stage s - 1
       FSTAMP(1, 2 + 3 * s);
@@ -1098,7 +1113,7 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
       auto request = [&](int i) {
         if (i >= 2 * NF) return;
         if (s + 2 < 8) issue_piece(cur, s + 2, i, slot_n);
-        else if (has_next) issue_piece(nxt, s - 6, i, slot_n);
+        else issue_piece(nxt, s - 6, i, slot_n);               // (last tile: nxt = cur, a re-read nobody uses)
       };
       // tables: the y-axis blocks replace the x-axis blocks once every wave has its x block in registers (stage 0); the
       // next tile's x blocks and scales replace them once every wave has its y blocks (stage 4)
@@ -1124,6 +1139,7 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) acc[a][8 * h + c8][jj] = c[jj];
         }
+        cw_mark_t((s + 2) % 3);                        // the pieces of stage s + 2 are all requested
         if (s == 3) {
           // ---- x part -> true units, then turned into the y layout ----
 #pragma unroll
@@ -1173,6 +1189,7 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
             }
           }
         }
+        cw_mark_t(s + 2 < 8 ? (s + 2) % 3 : (s - 6) % 3);      // the pieces of stage s + 2 (of the next tile: s - 6)
         if (!SKIP) store_rows(o, sy, 0);
       }
       FSTAMP(1, 3 + 3 * s);
@@ -1206,6 +1223,7 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
 #pragma unroll
         for (int k = 0; k < 4; ++k) store_rows(o, k, 1);        // the last tile's column block 1
       }
+      wait_vmcnt<0>();          // (the re-reads of the last two stages must have landed before the LDS is given back)
       break;
     }
     o_prev = o;
@@ -1217,12 +1235,275 @@ __global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis3_h2(const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// synthesis of both axes, 64 x 32 point tiles x 32 channels: whole 128-byte lines per store (round 4)
+// ------------------------------------------------------------------------------------------------------------
+// k_dft_synthesis3_h2 owns 16 channels of its points, so every store instruction writes sixteen 64-byte segments -- half
+// cache lines -- and a CU's memory pipeline takes such an instruction at a quarter of the rate of one that writes eight
+// whole 128-byte lines (profiles/ubench/storepat.hip: 37 vs 135 GB/s per CU); with the stores in, that kernel ran 225 us
+// against 100 us without them.  Here a workgroup owns a PAIR of channel blocks (32 channels = one 128-byte line per
+// point) of a 64-row x 32-column tile -- the same 128 accumulator registers per lane -- at the price of 2.25 instead of
+// 1.5 bytes of fragments fetched from L2 per byte stored (the fragments of a channel pair of a sample, 3.1 MB at 256^2,
+// still fit the XCD's L2 while all its tiles use them).
+//   * wave (mt, p) owns rows 16 mt .., columns 16 p .. of the tile for BOTH channel blocks a = 0, 1: acc[a][i][jj].
+//   * twelve stages of 16 (line, channel block) fragments through the same 3-slot ring: x stages 0-3 (channel block
+//     s >> 1, columns 8 (s & 1) .. + 7 of both column blocks), y stages 4-11 (rows 2 (s - 4), + 1 of the four row blocks,
+//     both channel blocks).  12 = 0 mod 3: the ring position is the same for every tile.
+//   * a row is final after its y stage and leaves right there: four store instructions per wave and y stage, each
+//     eight points x 128 bytes.  The 4 x 4 quad transpose that gives a lane four consecutive channels of one point
+//     takes its four inputs from BOTH channel blocks -- (a, column) = (0, 0), (0, 1), (1, 0), (1, 1) -- so the lanes
+//     of a quad end up with the two 64-byte halves of two points' lines: no exchange beyond the transpose itself.
+//   * forward and adjoint without a skip gradient (with one: k_dft_synthesis3_h2<.., true>).
+template <int S> struct StageC { static constexpr int value = S; };
+
+// Tried on top and dropped (same-box, 256^2, B = 32; profiles/r04_synthesis_variants.txt): requesting ALL pieces of stage
+// s + 2 right behind the barrier and issuing the stores of a stage's rows one stage later, behind the next requests, so
+// that a store has three stages instead of two to be acknowledged before a wait on younger pieces covers it (the counter
+// is in order) and no request queues behind a burst of stores: 225-230 us against 219 us.  Neither the store segment
+// (this kernel against k_dft_synthesis3_h2: 219 vs 224-235 us), nor the fragment volume (2.25 vs 1.5 bytes per byte
+// stored), nor the store window moves the time; the same store pattern alone streams at 6.2 TB/s = 87 us
+// (profiles/ubench/storepat.hip, pattern C / D).  What is left is that ONE workgroup per CU runs all its waves through
+// the same phase at the same time -- wait for pieces | fragments + matrix work | transposes + stores -- so the three
+// add up instead of overlapping.
+template <int K32, int TG>
+__global__ __launch_bounds__(64 * SYN3_WAVES, 2) void k_dft_synthesis4_h2(const SynP P) {
+  constexpr int NP = h2_np(TG), NF = 2 * K32 + NP;
+  constexpr int BB = NF * 1024;
+  constexpr long LB = 4L * BB;
+  constexpr int SLOT = 16 * BB;                 // one stage: 16 fragments
+  static_assert(NF <= 3, "ring of three 16-fragment slots + the table corner must fit 160 KB");
+  constexpr int TAB = 3 * SLOT, INV = TAB + 4 * BB, LDS_BYTES = INV + 512;
+  constexpr int NS = 12;                        // stages per tile
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = l >> 4, li = l & 15;
+  const int mt = w & 3, p = w >> 2;
+  const unsigned lane16 = l * 16;
+  typedef Frag<K32, TG> F;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+
+  // ---- items: (sample, channel pair, tile); group x = blockIdx % ng takes the samples x, x + ng, ..; within a sample all
+  // tiles of channel pair 0, then all of pair 1 (a pair's fragments stay in the group's L2 meanwhile)
+  const int tn = P.N >> 5, tiles = (P.M >> 6) * tn, wps = tiles * 2;
+  const int ng = P.sy;
+  const int xg = blockIdx.x % ng, jw = blockIdx.x / ng, nj = gridDim.x / ng;
+  const int nsamp = (P.B - xg + ng - 1) / ng;
+  const long nitems = (long)nsamp * wps;
+  auto item_at = [&](long q) {
+    Syn3Item it;
+    const int sb = (int)(q / wps), t = (int)(q - (long)sb * wps);
+    const int hb = t / tiles, tile = t - hb * tiles;
+    const int b = xg + ng * sb;
+    const int m0 = (tile / tn) << 6, n0 = (tile % tn) << 5;
+    it.gx = P.imgx + ((long)b * P.N + n0) * LB + (2 * hb) * BB;
+    it.gy = P.imgy + ((long)b * P.M + m0) * LB + (2 * hb) * BB;
+    it.tx = P.tabx + (long)(m0 >> 4) * BB;
+    it.ty = P.taby + (long)(n0 >> 4) * BB;
+    it.ivx = P.invx + (long)b * P.N + n0;
+    it.ivy = P.invy + (long)b * P.M + m0;
+    it.o = (((long)b * P.M + m0) * P.N + n0) * 64 + 32 * hb;
+    return it;
+  };
+  long q = jw;
+  if (q >= nitems) return;
+  Syn3Item cur = item_at(q);
+
+  // piece i (of 2 NF) of this wave for stage s of a tile
+  auto issue_piece = [&](const Syn3Item& it, int s, int i, int slot) {
+    const int idx = w + 8 * i, ell = idx / NF, f = idx - ell * NF;     // fragment ell of the stage, piece f of it
+    const char* src;
+    if (s < 4) src = it.gx + (long)(16 * (ell >> 3) + 8 * (s & 1) + (ell & 7)) * LB + (s >> 1) * BB + f * 1024;
+    else src = it.gy + (long)(16 * (ell >> 2) + 2 * (s - 4) + ((ell >> 1) & 1)) * LB + (ell & 1) * BB + f * 1024;
+    __builtin_amdgcn_global_load_lds((glb_ptr)(src + lane16), (lds_ptr)(smem + slot * SLOT + idx * 1024), 16, 0, 0);
+  };
+  // nblk consecutive 16-row blocks of a table (x axis: the tile's four row blocks; y axis: its two column blocks)
+  auto issue_table = [&](const char* tab, int nblk) {
+#pragma unroll
+    for (int i = 0; i < (4 * NF + 7) / 8; ++i) {
+      const int idx = w + 8 * i;
+      if (idx < nblk * NF)
+        __builtin_amdgcn_global_load_lds((glb_ptr)(tab + (long)idx * 1024 + lane16), (lds_ptr)(smem + TAB + idx * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_inv = [&](const Syn3Item& it) {          // 32 + 64 floats, one 4-byte DMA each
+    if (w == 6 && l < 32) __builtin_amdgcn_global_load_lds((glb_ptr)(it.ivx + l), (lds_ptr)(smem + INV), 4, 0, 0);
+    if (w == 7) __builtin_amdgcn_global_load_lds((glb_ptr)(it.ivy + l), (lds_ptr)(smem + INV + 256), 4, 0, 0);
+  };
+  auto lds_frag = [&](F& f, const char* base) {
+#pragma unroll
+    for (int s2 = 0; s2 < K32; ++s2) {
+      f.h[s2] = *reinterpret_cast<const f16x8*>(base + s2 * 1024);
+      f.lo[s2] = *reinterpret_cast<const f16x8*>(base + (K32 + s2) * 1024);
+    }
+#pragma unroll
+    for (int qq = 0; qq < NP; ++qq) f.pk[qq] = *reinterpret_cast<const f16x8*>(base + (2 * K32 + qq) * 1024);
+  };
+  auto chain = [&](const F& tab, const F& f) {
+    f32x4v c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qq = 0; qq < NP; ++qq) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab.pk[qq], f.pk[qq], c, 0, 0, 0);
+#pragma unroll
+    for (int s2 = K32 - 1; s2 >= 0; --s2) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab.lo[s2], f.h[s2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab.h[s2], f.lo[s2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab.h[s2], f.h[s2], c, 0, 0, 0);
+    }
+    return c;
+  };
+
+  // ---- prologue: tables / scales of the first tile, then its first two stages ----
+  issue_table(cur.tx, 4);
+  issue_inv(cur);
+#pragma unroll
+  for (int i = 0; i < 2 * NF; ++i) issue_piece(cur, 0, i, 0);
+  cw_mark<3>();                 // (tags 3 / 4: the first tile's stages 0 / 1, waited for under `first` -- a path-insensitive
+#pragma unroll                  //  check cannot know that `first` and "came from the prologue" are the same thing)
+  for (int i = 0; i < 2 * NF; ++i) issue_piece(cur, 1, i, 1);
+  cw_mark<4>();
+  bool first = true;
+  const int qd = li >> 2, pl = li & 3;
+  // acc[a][i][jj]: x phase -- channel block a, column i of the wave's column block, rows m = 4g + jj; after the turn,
+  // physical register [a][4 (r >> 2) + j][r & 3] holds row r, column 4g + j
+  float acc[2][16][4];
+
+  while (true) {
+    const long qn = q + nj;
+    const bool has_next = qn < nitems;
+    Syn3Item nxt = cur;
+    if (has_next) nxt = item_at(qn);
+    F tx, ty;
+    F fq[2];
+    float invx_l, invy_l;
+    // a lane's share of a store instruction: the two points (row r, column 16 p + 4 g + 2 h + (pl & 1)), h = 0, 1; of each
+    // the 16 bytes of channels 16 (pl >> 1) + 4 qd .. + 3 of the pair
+    const long o = cur.o + ((long)(16 * mt) * P.N + 16 * p + 4 * g + (pl & 1)) * 64 + 16 * (pl >> 1) + 4 * qd;
+    auto store_row = [&](long ob, int r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 v = make_float4(acc[0][4 * (r >> 2) + 2 * h][r & 3], acc[0][4 * (r >> 2) + 2 * h + 1][r & 3],
+                               acc[1][4 * (r >> 2) + 2 * h][r & 3], acc[1][4 * (r >> 2) + 2 * h + 1][r & 3]);
+        quad_transpose(v.x, v.y, v.z, v.w);
+        *reinterpret_cast<float4*>(P.out + ob + ((long)r * P.N + 2 * h) * 64) = v;
+      }
+    };
+    // (one call per stage with the stage number as a type: left as a loop of twelve the optimizer gives up unrolling the
+    //  instances with three fragment pieces, and the accumulators -- indexed by the stage -- go to scratch memory)
+    auto stage = [&](auto stage_c) {
+      constexpr int s = decltype(stage_c)::value;
+      // ---- this wave's pieces of stage s have landed: all but the N youngest operations of the wave are done; younger
+      // than the pieces of stage s are the stores of stage s - 2 (4 if it was a y stage), the pieces of stage s + 1
+      // (2 NF) and the stores of stage s - 1; table / scale pieces issued in between only make the wait longer
+      // (cw.h: tag = ring slot; tests/test_isa_counted_waits_cpu.py checks these counts on the compiled code)
+      constexpr int T = s % 3;
+      // (every stage requests its 2 NF pieces, the last tile's stages 10 / 11 a harmless re-read: the counts do not
+      //  depend on has_next)
+      if (s == 0) { if (first) cw_wait<3, 2 * NF>(); else cw_wait<T, 2 * NF + 8>(); }
+      else if (s == 1) { if (first) cw_wait<4, 2 * NF>(); else cw_wait<T, 2 * NF + 4>(); }
+      else if (s <= 4) cw_wait<T, 2 * NF>();
+      else if (s == 5) cw_wait<T, 2 * NF + 4>();
+      else cw_wait<T, 2 * NF + 8>();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's have; everyone is done with stage s - 1
+      const int slot_s = s % 3, slot_n = (s + 2) % 3;
+      auto request = [&](int i) {
+        if (i >= 2 * NF) return;
+        if (s + 2 < NS) issue_piece(cur, s + 2, i, slot_n);
+        else issue_piece(nxt, s + 2 - NS, i, slot_n);          // (last tile: nxt = cur, a re-read nobody uses)
+      };
+      // tables: the y-axis blocks replace the x-axis blocks once every wave has its x block in registers (stage 0); the
+      // next tile's x blocks and scales replace them once every wave has its y block (stage 4)
+      if (s == 1) issue_table(cur.ty, 2);
+      if (s == 5 && has_next) { issue_table(nxt.tx, 4); issue_inv(nxt); }
+      const char* slot = smem + slot_s * SLOT + l * 16;
+      if (s < 4) {
+        const int a = s >> 1, h = s & 1;
+        if (s == 0) {
+          lds_frag(tx, smem + TAB + mt * BB + l * 16);
+          invx_l = *reinterpret_cast<const float*>(smem + INV + (16 * p + li) * 4);
+          invy_l = *reinterpret_cast<const float*>(smem + INV + 256 + (16 * mt + li) * 4);
+        }
+        lds_frag(fq[0], slot + (p * 8) * BB);
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+          if (c8 + 1 < 8) lds_frag(fq[(c8 + 1) & 1], slot + (p * 8 + c8 + 1) * BB);
+          asm volatile("" ::: "memory");
+          const f32x4v c = chain(tx, fq[c8 & 1]);
+          request(c8);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[a][8 * h + c8][jj] = c[jj];
+        }
+        cw_mark<(s + 2) % 3>();                        // the pieces of stage s + 2 are all requested
+        if (s == 3) {
+          // ---- x part -> true units, then turned into the y layout (k_dft_synthesis3_h2's turn) ----
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(invx_l), i));
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) acc[a2][i][jj] *= sc;
+            }
+#pragma unroll
+            for (int jy = 0; jy < 4; ++jy)
+#pragma unroll
+              for (int jr = 0; jr < 4; ++jr) {
+                swap_halves(acc[a2][jy][jr], acc[a2][8 + jy][jr]);
+                swap_halves(acc[a2][4 + jy][jr], acc[a2][12 + jy][jr]);
+                swap_rows(acc[a2][jy][jr], acc[a2][4 + jy][jr]);
+                swap_rows(acc[a2][8 + jy][jr], acc[a2][12 + jy][jr]);
+              }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) pin(acc[a2][i][jj]);
+          }
+        }
+      } else {
+        const int sy = s - 4;
+        if (sy == 0) lds_frag(ty, smem + TAB + p * BB + l * 16);
+        lds_frag(fq[0], slot + (mt * 4) * BB);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                   // fragment mt * 4 + e: row 2 sy + (e >> 1), channel block e & 1
+          const int r = 2 * sy + (e >> 1), a = e & 1;
+          if (e + 1 < 4) lds_frag(fq[(e + 1) & 1], slot + (mt * 4 + e + 1) * BB);
+          asm volatile("" ::: "memory");
+          const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(invy_l), r));
+          const f32x4v c = chain(ty, fq[e & 1]);
+          request(2 * e);
+          request(2 * e + 1);                           // (2 NF <= 6 pieces: all out before the stage's stores)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[a][4 * (r >> 2) + j][r & 3] = fmaf(c[j], sc, acc[a][4 * (r >> 2) + j][r & 3]);
+            pin(acc[a][4 * (r >> 2) + j][r & 3]);
+          }
+        }
+        cw_mark<(s + 2) % 3>();                        // the pieces of stage s + 2 (of the next tile: s + 2 - 12)
+        store_row(o, 2 * sy);
+        store_row(o, 2 * sy + 1);
+      }
+    };
+    stage(StageC<0>{}); stage(StageC<1>{}); stage(StageC<2>{}); stage(StageC<3>{});
+    stage(StageC<4>{}); stage(StageC<5>{}); stage(StageC<6>{}); stage(StageC<7>{});
+    stage(StageC<8>{}); stage(StageC<9>{}); stage(StageC<10>{}); stage(StageC<11>{});
+    if (!has_next) {
+      wait_vmcnt<0>();          // (the re-reads of the last two stages must have landed before the LDS is given back)
+      break;
+    }
+    cur = nxt;
+    q = qn;
+    first = false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 bool fused2d_ok(int M, int N, int C, int keff_y, int keff_x) {
   const int Ry = 2 * ((keff_y + 3) / 4 * 4), Rx = 2 * ((keff_x + 3) / 4 * 4);
   if (const char* e = getenv("RPDE_FUSED_SPECTRAL")) if (e[0] == '0') return false;
-  return C == 64 && M % 32 == 0 && N % 32 == 0 && M <= 32 * ANA_MAXKS && N <= 32 * ANA_MAXKS && Ry == Rx && Ry <= 48;
+  // keff_y == keff_x, not only equal padded counts: the h2 mode mix (k_mix_prep, k_mix_wgrad_fold) zeroes the weights and
+  // gradients of modes >= keff with ONE keff for both axes, while the reference clamps each axis by its own length
+  // (spectral_convolution.py:269-300) -- e.g. a [64, 32] grid with 20 modes keeps 17 along y and 20 along x
+  return C == 64 && M % 32 == 0 && N % 32 == 0 && M <= 32 * ANA_MAXKS && N <= 32 * ANA_MAXKS && keff_y == keff_x && Ry == Rx &&
+         Ry <= 48;
 }
 
 size_t fused2d_img_bytes(long lines, int R) { return (size_t)lines * 4 * h2_block_bytes(R / 32, (R % 32) / 8); }
@@ -1259,6 +1540,7 @@ int fused2d_analysis(const float* x, float* spec_y, float* spec_x, float* amax_y
       AnaSqP Q;
       Q.x = x; Q.timg = (const char*)py->h2_ana_p[adjoint]; Q.spec_y = spec_y; Q.spec_x = spec_x; Q.amax_y = amax_y; Q.amax_x = amax_x;
       Q.B = B; Q.n = N; Q.ks = N / 32; Q.R = 2 * py->kp;
+      { const char* e = getenv("RPDE_ANA_B1"); Q.b1 = (e && e[0] == '1') ? 1 : 0; }
       Q.rpw = ANA_WAVES / Q.ks;                            // rows of a block per workgroup; 32 / rpw workgroups per group
       const int wpg = 32 / Q.rpw;
       Q.ng = B < 256 / wpg ? B : 256 / wpg;
@@ -1306,6 +1588,12 @@ int fused2d_split(const float* spec, void* img, float* inv, long lines, int R, h
   return RPDE_OK;
 }
 
+// RPDE_SYN4=0: keep the 64 x 64 x 16-channel tile kernel where the 64 x 32 x 32-channel one would run (A/B, tests)
+static bool syn4_on() {
+  const char* e = getenv("RPDE_SYN4");
+  return !(e && e[0] == '0');
+}
+
 // RPDE_SYN3=0: keep the 16 x 16 tile kernel for every shape (A/B, tests)
 static bool syn3_ok(int M, int N) {
   if (const char* e = getenv("RPDE_SYN3")) if (e[0] == '0') return false;
@@ -1324,6 +1612,27 @@ int fused2d_synthesis(const void* imgy, const void* imgx, const float* invy, con
     int dev = 0, cus = 256;
     RPDE_HIP(hipGetDevice(&dev));
     RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (!skip && syn4_on()) {
+      // 64 x 32 x 32-channel tiles, whole 128-byte lines per store: (M / 64) (N / 32) 2 items per sample
+      const int ng = B < 8 ? B : 8;
+      P.sy = ng;
+      P.sx = 1;
+      const long wps = (long)(M / 64) * (N / 32) * 2;
+      long per_group = cus / ng;
+      const long most = (long)((B + ng - 1) / ng) * wps;
+      if (per_group > most) per_group = most;
+      if (per_group < 1) per_group = 1;
+      const dim3 grid4((unsigned)(ng * per_group)), blk4(64 * SYN3_WAVES);
+      switch (R3 / 8) {
+        case 1: hipLaunchKernelGGL((k_dft_synthesis4_h2<0, 1>), grid4, blk4, 0, st, P); break;
+        case 2: hipLaunchKernelGGL((k_dft_synthesis4_h2<0, 2>), grid4, blk4, 0, st, P); break;
+        case 3: hipLaunchKernelGGL((k_dft_synthesis4_h2<0, 3>), grid4, blk4, 0, st, P); break;
+        case 4: hipLaunchKernelGGL((k_dft_synthesis4_h2<1, 0>), grid4, blk4, 0, st, P); break;
+        default: hipLaunchKernelGGL((k_dft_synthesis4_h2<1, 1>), grid4, blk4, 0, st, P); break;
+      }
+      RPDE_LAUNCH_CHECK();
+      return RPDE_OK;
+    }
     // persistent: one workgroup per CU, in 8 groups (one per XCD; fewer when the batch is smaller); never more per group
     // than the busiest group has tiles
     const int ng = B < 8 ? B : 8;

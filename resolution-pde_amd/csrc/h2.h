@@ -93,9 +93,14 @@ __device__ __forceinline__ f32x4v h2_mfma32(f16x8 ah, f16x8 al, f16x8 bh, f16x8 
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
 }
-// (There is deliberately no 16-deep variant on v_mfma_f32_16x16x16_f16: on gfx950 / ROCm 7.2 a dependent accumulator chain
-//  that mixed it with the 32-deep form read wrong accumulator registers in the fused synthesis kernel; short reduction
-//  tails are packed into 32-deep fragments instead -- fused_spectral.hip, h2_store_tail.)
+// (There is deliberately no 16-deep variant on v_mfma_f32_16x16x16_f16.  Round 2 saw wrong accumulators when the fused
+//  synthesis kernel closed a 32-deep chain with a 16-deep tail; round 4 reduced it to two instructions
+//  (profiles/ubench/mfma_mix.hip, output + disassembly in profiles/r04_mfma_mix.txt): ROCm 7.2 emits
+//  `v_mfma_f32_16x16x32_f16 v[0:3], ..` and the dependent `v_mfma_f32_16x16x16_f16 v[0:3], .., v[0:3]` back to back and
+//  half of the result is wrong; with s_nop padding between them, or in the order 16-deep -> 32-deep, it is exact.  The
+//  shorter instruction reads its SrcC before the longer one has written all of it, and neither the hardware nor the
+//  compiler's hazard recognizer waits for this opcode pair.  Same-shape chains are handled.  Short reduction tails are
+//  therefore packed into 32-deep fragments -- fused_spectral.hip, h2_store_tail -- which also costs no padding.)
 
 // LDS accesses of one wave to its private staging area: the hardware executes a wave's DS instructions in order;
 // this only keeps the compiler from reordering a lane's read above another lane's write

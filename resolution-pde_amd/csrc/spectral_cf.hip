@@ -607,9 +607,9 @@ size_t rpde_fnoblock2d_eval_ws_bytes(int B, int Cin, int Cout, int M, int N, int
   return rpde_spectral2d_ws_bytes(B, Cin, Cout, M, N, m1, m2) + arena_bytes(rpde_spectral2d_spec_elems(B, Cin, M, N, m1, m2));
 }
 
-int rpde_fnoblock2d_eval_ok(int Cin, int Cout, int M, int N) {
+int rpde_fnoblock2d_eval_ok(int Cin, int Cout, int M, int N, int m2) {
   // (pointer alignment is checked at the call; torch allocations are 256-byte aligned)
-  return conv1x1_syn_ok(nullptr, nullptr, Cin, Cout, M, N) ? 1 : 0;
+  return conv1x1_syn_ok(nullptr, nullptr, Cin, Cout, M, N, 2 * ((m2 + 3) / 4 * 4)) ? 1 : 0;
 }
 
 int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc, float* out, int B,
@@ -621,7 +621,7 @@ int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, c
     set_error("SpectralConv2d: modes (%d,%d) exceed the spectrum (%d,%d)", m1, m2, M, N / 2 + 1);
     return RPDE_ERR_MODES;
   }
-  RPDE_CHECK_ARG(conv1x1_syn_ok(x, out, Cin, Cout, M, N), "fnoblock2d_eval_fwd: shape not covered (%d -> %d on %d x %d)", Cin, Cout, M, N);
+  RPDE_CHECK_ARG(conv1x1_syn_ok(x, out, Cin, Cout, M, N, 2 * ((m2 + 3) / 4 * 4)), "fnoblock2d_eval_fwd: shape not covered (%d -> %d on %d x %d)", Cin, Cout, M, N);
   hipStream_t st = as_stream(stream);
   const rpde_plan *pn, *pm;
   RPDE_TRY(get_plan(&pn, N, m2, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));

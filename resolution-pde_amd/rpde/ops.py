@@ -37,9 +37,17 @@ def _as_float_storage(w: torch.Tensor) -> torch.Tensor:
 # ``with frozen_weights():`` the no-grad paths of the FeedForward and of the 2-D spectral layer build their weight
 # fragments (weight-norm / f16 pieces / mode-mix B operands) ONCE per layer and reuse them; the scope's end drops them.
 # Contract: inside the scope the weights are changed, if at all, by torch in-place ops (which bump ``_version`` and
-# refresh the entry) -- not by a kernel writing through a raw pointer (FlatAdamW.step: do not step inside the scope).
+# refresh the entry) or by FlatAdamW.step, which writes through raw pointers and therefore calls
+# ``invalidate_frozen()`` itself; any other raw-pointer writer must do the same.
 # ----------------------------------------------------------------------------
 _FROZEN: Optional[dict] = None
+
+
+def invalidate_frozen() -> None:
+    """drop every prepared buffer of the open scope (the scope itself stays open): for code that changes parameters
+    without bumping ``_version`` -- FlatAdamW.step, a load through raw pointers"""
+    if _FROZEN is not None:
+        _FROZEN.clear()
 
 
 @contextlib.contextmanager
@@ -55,10 +63,15 @@ def frozen_weights():
             _FROZEN = None
 
 
-def _frozen_entry(kind, tensors, extra, nbytes, build):
+def _frozen_entry(kind, tensors, extra, nbytes, build, originals=None):
     """prepared buffer for these weight tensors, built by build(buf) on first use; None when no scope is open (or while
     a HIP graph is being captured: a graph must not hold a pointer whose life ends with the scope)"""
     if _FROZEN is None or torch.cuda.is_current_stream_capturing():
+        return None
+    # originals: what the caller was handed before _f32c.  Where _f32c had to copy (a parameter in another dtype or
+    # layout) the copy has a new address on every call: caching by it would re-prepare every time and keep every copy
+    # alive until the scope ends -- such weights take the unprepared path.
+    if originals is not None and any(t is not o for t, o in zip(tensors, originals)):
         return None
     key = (kind, extra) + tuple(t.data_ptr() for t in tensors)
     ver = tuple(t._version for t in tensors)
@@ -173,7 +186,7 @@ def _fspectral2d_frozen(x, wy, wx, modes: int):
     wyf, wxf = _f32c(wy), _f32c(wx)
     prep = _frozen_entry("fs2d", (wyf, wxf), (M, N, Cc, modes), npre, lambda buf: check(
         lib.rpde_fspectral2d_prepare(ptr(wyf), ptr(wxf), M, N, Cc, modes, buf.data_ptr(), npre, stream_ptr()),
-        "fspectral2d_prepare"))
+        "fspectral2d_prepare"), originals=(wy, wx))
     if prep is None:
         return None
     out = torch.empty_like(x)
@@ -227,7 +240,9 @@ class _FeedForward(torch.autograd.Function):
         need_grad = grad_on and any(ctx.needs_input_grad)     # (grad mode is always off inside forward itself)
         hid = dim * factor
         # the fused kernel keeps the hidden activations on chip: in evaluation nothing but `out` is allocated
-        fused = bool(lib.rpde_feedforward_is_fused(dim, factor, L, P))
+        # (the fused kernels' weight preparation reads 16 bytes at a time: a weight view at an odd storage offset takes the
+        #  per-GEMM path inside the library, which needs the hidden buffers -- so it must not be "lean" here either)
+        fused = bool(lib.rpde_feedforward_is_fused(dim, factor, L, P)) and all(w.data_ptr() % 16 == 0 for w in ws_)
         lean = (not need_grad) and fused
         # RPDE_FF_STASH=u: training through the fused kernels saves only u = dropout(z) of the hidden layers (in `hs`) and
         # the backward kernels re-evaluate gelu / gelu' from it -- half the saved-for-backward footprint, but measured
@@ -246,8 +261,11 @@ class _FeedForward(torch.autograd.Function):
         nws = lib.rpde_feedforward_fwd_ws_bytes(dim, factor, L)
         if lean and p_drop == 0.0:
             held = tuple(ws_ + bs_ + ([gamma, beta] if layer_norm else []))
+            orig = tuple([params[2 * l] for l in range(L)] + [params[2 * l + 1] for l in range(L)] +
+                         ([params[2 * L], params[2 * L + 1]] if layer_norm else []))
             prep = _frozen_entry("ff", held, (L, dim, factor), nws, lambda buf: check(
-                lib.rpde_feedforward_prepare(C.byref(fp), buf.data_ptr(), nws, stream_ptr()), "feedforward_prepare"))
+                lib.rpde_feedforward_prepare(C.byref(fp), buf.data_ptr(), nws, stream_ptr()), "feedforward_prepare"),
+                originals=orig)
             if prep is not None:
                 check(lib.rpde_feedforward_fwd_prepared(C.byref(fp), ptr(x2), ptr(res2), ptr(out), P, prep.data_ptr(), nws,
                                                         stream_ptr()), "feedforward_fwd_prepared")
@@ -509,7 +527,7 @@ def fnoblock2d_eval(x, w1, w2, wc, bc, act_out: str):
         return None
     B, Ci, M, N = x.shape
     Co, m1, m2 = w1.shape[1], w1.shape[2], w1.shape[3]
-    if not lib.rpde_fnoblock2d_eval_ok(Ci, Co, M, N):
+    if not lib.rpde_fnoblock2d_eval_ok(Ci, Co, M, N, m2):
         return None
     x = _f32c(x)
     wcf = _f32c(wc.detach()).reshape(Co, Ci)

@@ -86,6 +86,10 @@ class FlatAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], float(g["eps"]), float(g["weight_decay"])
         self.bucket.gather()                                    # gradients into the flat buffer (no-op when done)
+        # the update kernels write the parameters through raw pointers (no _version bump): prepared weight fragments of an
+        # open rpde.ops.frozen_weights() scope would go stale silently
+        from . import ops as _ops
+        _ops.invalidate_frozen()
         params = self.bucket.params
         lib, st = load(), stream_ptr()
         base_g = self.bucket.flat.data_ptr()

@@ -6,6 +6,9 @@ from __future__ import annotations
 
 FFNO2D_CFG3 = dict(in_channels=1, out_channels=1, width=64, n_layers=4, n_modes=20, factor=4,
                    ff_weight_norm=True, n_ff_layers=3, layer_norm=True, dropout=0.0)
+# the reference's shipped conf/model/ffno_2d/ffno_2d.yaml (n_modes: 64; dropout 0.1 there, 0 here for parity)
+FFNO2D_YAML = dict(in_channels=1, out_channels=1, width=64, n_layers=4, n_modes=64, factor=4,
+                   ff_weight_norm=True, n_ff_layers=3, layer_norm=True, dropout=0.0)
 FFNO1D_YAML = dict(in_channels=1, out_channels=1, width=128, n_layers=4, n_modes=64, factor=4,
                    ff_weight_norm=True, n_ff_layers=3, layer_norm=True, dropout=0.0,
                    mode="full", activation="gelu", use_grid=True)
@@ -54,6 +57,9 @@ CASES = [
          ctor=dict(d_model=64, modes=20, factor=4, n_ff_layers=3, layer_norm=True), x=(1, 128, 128, 64), seed=403),
     dict(name="fs2d_r256", kind="FSpectralConv2d",
          ctor=dict(d_model=64, modes=20, factor=4, n_ff_layers=3, layer_norm=True), x=(1, 256, 256, 64), seed=404),
+    # 64 retained modes (the shipped yaml's n_modes): all 65 bins but the Nyquist one at 128
+    dict(name="fs2d_r128_k64", kind="FSpectralConv2d",
+         ctor=dict(d_model=64, modes=64, factor=4, n_ff_layers=3, layer_norm=True), x=(1, 128, 128, 64), seed=408),
     dict(name="fs2d_rect_small", kind="FSpectralConv2d",
          ctor=dict(d_model=8, modes=5, factor=2, n_ff_layers=2, layer_norm=True), x=(2, 24, 40, 8), seed=405),
     dict(name="fs2d_fork", kind="FSpectralConv2d",
@@ -101,6 +107,9 @@ CASES = [
     # the headline configuration at a real batch (P = 524 288 grid points per layer; ~9 GB of autograd state in the
     # reference run): pins batch handling -- slab counts, grid decompositions, 64-bit offsets -- against the reference
     dict(name="ffno2d_cfg3_256_b8", kind="FFNO2D", ctor=FFNO2D_CFG3, x=(8, 1, 256, 256), seed=515),
+    # the shipped yaml: at 64^2 the 64 modes clamp to 33 (every bin), at 256^2 they are half of the spectrum
+    dict(name="ffno2d_yaml_64", kind="FFNO2D", ctor=FFNO2D_YAML, x=(1, 1, 64, 64), seed=516),
+    dict(name="ffno2d_yaml_256", kind="FFNO2D", ctor=FFNO2D_YAML, x=(1, 1, 256, 256), seed=517),
     dict(name="ffno2d_small_nowm", kind="FFNO2D",
          ctor=dict(in_channels=2, out_channels=3, width=16, n_layers=2, n_modes=5, factor=2, ff_weight_norm=False,
                    n_ff_layers=2, layer_norm=False, dropout=0.0, use_grid=False),

@@ -94,10 +94,29 @@ def sample_index(numel: int) -> np.ndarray:
     return np.random.RandomState(numel % (2 ** 31 - 1)).randint(0, numel, N_SAMPLE)
 
 
+N_PROJ = 4              # full-tensor checksums: projections onto seeded Gaussian vectors
+
+
+def projections(f: np.ndarray) -> np.ndarray:
+    """f . r_j for N_PROJ seeded standard-normal vectors r_j (float64).  An error e anywhere in the tensor moves a
+    projection by about |e|_2, so -- unlike the sampled scalars -- no tile can be wrong unseen: the sampled scalars
+    say WHERE the values agree, the projections that nothing else differs."""
+    out = np.empty(N_PROJ)
+    for j in range(N_PROJ):
+        rs = np.random.RandomState((f.size * 7919 + 104729 * j + 13) % (2 ** 31 - 1))
+        acc, step = 0.0, 1 << 22
+        for lo in range(0, f.size, step):                       # (chunked: the generator's draws are sequential)
+            acc += float(f[lo:lo + step] @ rs.standard_normal(min(step, f.size - lo)))
+        out[j] = acc
+    return out
+
+
 def digest(t: torch.Tensor) -> Dict[str, np.ndarray]:
     f = _flat64(t)
     d = {"norm": np.array(np.sqrt((f * f).sum())), "sum": np.array(f.sum()),
          "numel": np.array(f.size)}
+    if f.size > FULL_LIMIT:
+        d["proj"] = projections(f)
     if f.size <= FULL_LIMIT:
         d["full"] = f.astype(np.float32)
     else:
@@ -116,7 +135,10 @@ def compare(t: torch.Tensor, d: Mapping[str, np.ndarray]) -> float:
     e_samp = float(np.sqrt(((got - ref) ** 2).sum()) / den)
     n_ref = float(d["norm"])
     e_norm = abs(float(np.sqrt((f * f).sum())) - n_ref) / (n_ref + 1e-30)
-    return max(e_samp, e_norm)
+    e_proj = 0.0
+    if "proj" in d:
+        e_proj = float(np.sqrt(((projections(f) - d["proj"].astype(np.float64)) ** 2).mean())) / (n_ref + 1e-30)
+    return max(e_samp, e_norm, e_proj)
 
 
 def check_results(res: Mapping[str, torch.Tensor], digests: Mapping[str, Mapping[str, np.ndarray]],

@@ -84,9 +84,9 @@ def test_rollout_and_sweep_use_the_scope(gpu_device, monkeypatch):
     seen = []
     real = ops._frozen_entry
 
-    def spy(kind, tensors, extra, nbytes, build):
+    def spy(kind, tensors, extra, nbytes, build, originals=None):
         built = []
-        r = real(kind, tensors, extra, nbytes, lambda buf: (built.append(1), build(buf)))
+        r = real(kind, tensors, extra, nbytes, lambda buf: (built.append(1), build(buf)), originals=originals)
         seen.append((kind, bool(built)))
         return r
 

@@ -59,6 +59,35 @@ def test_fused_spectral_equals_gemm_path(gpu_device, shape, scale):
         assert _rel(a, b) < 2e-6, (name, _rel(a, b))
 
 
+def test_rectangular_grid_clamps_modes_per_axis(gpu_device):
+    """[M >= 64, N = 32] with 20 modes: 17 bins survive along y, 20 along x, both pad to 20 -- the fused path's mode mix
+    knows ONE clamp for both axes, so this shape must not take it (round-3 advisor finding: x-axis modes 17..19 got zero
+    weights and zero gradients).  Checked against torch.fft in float64, forward and the x-axis weight gradient."""
+    B, M, N, K = 2, 64, 32, 20
+    torch.manual_seed(5)
+    x = torch.randn(B, M, N, 64, device=gpu_device)
+    wy = torch.randn(64, 64, K, 2, device=gpu_device) * 0.1
+    wx = torch.randn(64, 64, K, 2, device=gpu_device) * 0.1
+    g = torch.randn(B, M, N, 64, device=gpu_device)
+    out, dx, dwy, dwx = _spectral(x, wy, wx, K, g)
+
+    xr = x.detach().cpu().double().permute(0, 3, 1, 2).requires_grad_(True)
+    wyr, wxr = wy.cpu().double().requires_grad_(True), wx.cpu().double().requires_grad_(True)
+    ky, kx = min(K, N // 2 + 1), min(K, M // 2 + 1)
+    fy = torch.fft.rfft(xr, dim=-1, norm="ortho")
+    oy = fy.new_zeros(B, 64, M, N // 2 + 1)
+    oy[..., :ky] = torch.einsum("bixy,ioy->boxy", fy[..., :ky], torch.view_as_complex(wyr[:, :, :ky]))
+    fx = torch.fft.rfft(xr, dim=-2, norm="ortho")
+    ox = fx.new_zeros(B, 64, M // 2 + 1, N)
+    ox[:, :, :kx] = torch.einsum("bixy,iox->boxy", fx[:, :, :kx], torch.view_as_complex(wxr[:, :, :kx]))
+    ref = (torch.fft.irfft(oy, n=N, dim=-1, norm="ortho") + torch.fft.irfft(ox, n=M, dim=-2, norm="ortho")).permute(0, 2, 3, 1)
+    ref.backward(g.cpu().double())
+    assert _rel(out.cpu(), ref.detach()) < 2e-6
+    assert _rel(dwx.cpu(), wxr.grad) < 5e-6 and _rel(dwy.cpu(), wyr.grad) < 5e-6
+    assert float(dwx[:, :, 17:].abs().max()) > 0           # the x axis keeps all 20 modes
+    assert float(dwy[:, :, 17:].abs().max()) == 0          # the y axis (n = 32) only 17
+
+
 def test_fused_spectral_lowpass_and_skip_gradient(gpu_device):
     from rpde import ops
     torch.manual_seed(3)
