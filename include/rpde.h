@@ -109,6 +109,9 @@ typedef struct {
   /* with accumulate: add this tensor (same layout and strides as C) instead of the old contents of C,
    * i.e. C = alpha*A.B + acc_src -- sums a skip-connection gradient without a separate pass */
   const float* acc_src;
+  /* optional device counter folded into drop_seed by the kernel (8 bytes, read once per launch): lets a captured
+   * hipGraph draw new masks at every replay -- see rpde_ff_params.seed_epoch */
+  const uint64_t* drop_epoch;
 } rpde_gemm_desc;
 int rpde_gemm_f32(const rpde_gemm_desc* d, void* stream);
 
@@ -204,6 +207,12 @@ typedef struct {
   const float* const* weights;         /* [n_layers] W_l [out_l, in_l]               */
   const float* const* biases;          /* [n_layers] b_l [out_l]                     */
   const float* ln_gamma; const float* ln_beta;
+  /* optional (may be NULL): device address of a 64-bit counter that every kernel of the call mixes into the seed.
+   * A hipGraph replays its launch arguments, so a host-drawn seed alone would repeat one mask for ever; the training
+   * step advances this counter on the device once per step (between backward and the next forward), and forward and
+   * backward of a step read the same value.  The reference draws its masks from torch's generator
+   * (models/custom_layer.py:60, nn.Dropout): parity is statistical either way. */
+  const uint64_t* seed_epoch;
 } rpde_ff_params;
 size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers);      /* backward */
 /* forward scratch (optional: ws may be NULL; with it each weight is pre-split once per call for the

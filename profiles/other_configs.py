@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Timing of the other BASELINE configs (parity-test cases, not bench lines): train step of FNO1d (cfg0) and
-FFNO1D (cfg1), eval forward + 5-step rollout of FNO2d at 512^2 (cfg4).  GPU events, synthetic data."""
+FFNO1D (cfg1), eval forward + 5-step rollout of FNO2d at 512^2 (cfg4); round 4: the reference's SHIPPED FFNO2D yaml
+(conf/model/ffno_2d/ffno_2d.yaml: n_modes 64 -- off the fused spectral path) beside the stock-ATen
+run of the same op sequence on this GPU.  GPU events, synthetic data.
+    python profiles/other_configs.py [yaml]        (yaml: only the shipped-yaml section)"""
 import os
 import sys
 import time
@@ -47,6 +50,51 @@ def graphed(model, x, y):
     return lambda: step(x, y)
 
 
+
+
+def shipped_yaml():
+    """FFNO2D(width 64, 4 layers, n_modes 64, 3 FeedForward layers, LayerNorm, dropout 0.1) at 256^2: the training step and
+    one layer's forward_fourier, this library against the oracle's op sequence on stock ATen (rocFFT + hipBLASLt)"""
+    sys.path.insert(0, REPO)
+    from models.ffno import FFNO2D
+    from oracle import reference_path as R          # baseline leg only (as bench.py's gpu_aten_baseline)
+    from rpde import ops
+    cfg = dict(in_channels=1, out_channels=1, width=64, n_layers=4, n_modes=64, factor=4, ff_weight_norm=True,
+               n_ff_layers=3, layer_norm=True, dropout=0.1)
+    K = 64
+    for B in (8, 32):
+        x = torch.randn(B, 256, 256, 64, device=dev)
+        wy = torch.randn(64, 64, K, 2, device=dev) * 0.1
+        wx = torch.randn(64, 64, K, 2, device=dev) * 0.1
+        alg = 4.0 * B * 256 * 256 * 2 * 64 + 2 * 8.0 * 64 * 64 * K
+        with torch.no_grad():
+            ms = timed(lambda: ops.fspectral2d(x, wy, wx, K), iters=10, warm=3)
+            ma = timed(lambda: R.fspectral2d_fourier(x, wy, wx, K), iters=5, warm=2)
+        print(f"yaml FSpectralConv2d.forward_fourier K=64 256^2 B={B:3d}: {ms:8.3f} ms = {alg / ms / 1e6:7.0f} GB/s algorithmic "
+              f"(frac of 8 TB/s {alg / ms / 1e6 / 8000:.3f}) | stock ATen {ma:8.3f} ms  x{ma / ms:.1f}", flush=True)
+        del x
+        torch.manual_seed(0)
+        m = FFNO2D(**cfg).to(dev).train()
+        xb = torch.randn(B, 1, 256, 256, device=dev)
+        yb = torch.randn_like(xb)
+        ms = timed(train_step(m, xb, yb), iters=10, warm=3)
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        params = R.make_params(sd)
+        opt = torch.optim.AdamW(list(params.values()), lr=1e-3)
+
+        def astep():
+            opt.zero_grad()
+            R.relative_l2(R.ffno2d_forward(params, xb, 4, K, 3, True, 0.1, training=True), yb).backward()
+            opt.step()
+        ma = timed(astep, iters=3, warm=2)
+        print(f"yaml FFNO2D(n_modes 64) 256^2 train step  B={B:3d}: {ms:8.3f} ms/step {B / ms * 1e3:8.1f} samples/s | stock ATen "
+              f"{ma:8.3f} ms/step {B / ma * 1e3:8.1f} samples/s  x{ma / ms:.1f}", flush=True)
+        del m, params, opt
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "yaml":
+    shipped_yaml()
+    raise SystemExit(0)
 torch.manual_seed(0)
 m = FNO1d(1, 1, modes=16, width=64).to(dev).train()
 for B in (16, 256):
@@ -76,3 +124,5 @@ for B in (4, 16):
                 s = m(s)
         ms = timed(roll, iters=5)
         print(f"cfg4 FNO2d 512^2 5-step rollout B={B}: {ms:8.3f} ms", flush=True)
+del m, x
+shipped_yaml()

@@ -47,7 +47,7 @@ static inline int wgrad_split(long P, int out_f, int in_f) {
 static inline bool worth_presplit(long P, int n, int k) { return P >= 1024 && k % 32 == 0 && n > 32; }
 static int linear_fwd_impl(const float* x, const float* w, const float* b, float* y, long P, int in_f, int out_f,
                            int act_out, float* dy, float drop_p, uint64_t drop_seed, hipStream_t st,
-                           void* wimg = nullptr) {
+                           void* wimg = nullptr, const uint64_t* drop_epoch = nullptr) {
   if (act_out == RPDE_ACT_IDENTITY && !dy && drop_p == 0.f) {
     // lifting / projection shapes: streaming kernels instead of degenerate GEMMs (thin_linear.hip)
     if (in_f <= 4 && thin_linear_ok(in_f, out_f) && al16(y)) return thin_expand(x, w, in_f, 1, b, y, P, in_f, out_f, st);
@@ -64,7 +64,7 @@ static int linear_fwd_impl(const float* x, const float* w, const float* b, float
   d.M = (int)P; d.N = out_f; d.K = in_f;
   d.bias = b; d.bias_mode = b ? 1 : 0;
   d.write_act = act_out; d.aux_out = act_out ? dy : nullptr;
-  if (act_out) { d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = out_f; d.drop_where = 4; }
+  if (act_out) { d.drop_p = drop_p; d.drop_seed = drop_seed; d.drop_ld = out_f; d.drop_where = 4; d.drop_epoch = drop_epoch; }
   return launch_gemm(d, st);
 }
 
@@ -229,10 +229,10 @@ int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* r
     const float* in = l == 0 ? x : hs[l - 1];
     RPDE_TRY(linear_fwd_impl(in, p->weights[l], p->biases ? p->biases[l] : nullptr, last ? z_last : hs[l], P, ff_in(p, l),
                              ff_out(p, l), last ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU, (last || !ds) ? nullptr : ds[l],
-                             p->dropout_p, layer_seed(p->seed, l), st, wimg));
+                             p->dropout_p, layer_seed(p->seed, l), st, wimg, p->seed_epoch));
   }
   return ff_tail_fwd(z_last, residual, out, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
-                     make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, st);
+                     make_drop(p->dropout_p, layer_seed(p->seed, L - 1), p->seed_epoch), p->post_act, st);
 }
 
 int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* const* hs, const float* const* ds,
@@ -299,7 +299,7 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   float* other = buf1;
   int bias_done = 0;      // grad_biases[l] already produced by the kernel that produced dz_l
   RPDE_TRY(ff_tail_bwd(z_last, grad_out, dz, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
-                       make_drop(p->dropout_p, layer_seed(p->seed, L - 1)), p->post_act, grad_gamma, grad_beta,
+                       make_drop(p->dropout_p, layer_seed(p->seed, L - 1), p->seed_epoch), p->post_act, grad_gamma, grad_beta,
                        grad_biases ? grad_biases[L - 1] : nullptr, &bias_done, small, st));
   for (int l = L - 1; l >= 0; --l) {
     const int in_f = ff_in(p, l), out_f = ff_out(p, l);

@@ -196,8 +196,11 @@ __device__ __forceinline__ void ff_put_frag(char* dst, const float (&v)[8]) {
 // kernel and the weight-gradient kernels re-evaluate gelu' / gelu while the data passes through them, which halves
 // this kernel's stores and the saved-for-backward footprint
 template <int MODE>
-__global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A) {
+__global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_fwd_h2(const FF3P A0) {
   constexpr bool TRAIN = MODE != 0;
+  FF3P A = A0;                                                  // (the masks' device-side counter folded into the seeds)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) A.drop[i] = drop_resolve(A0.drop[i]);
   __shared__ __attribute__((aligned(16))) char smem[FF_LDS];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, li = l & 15;
   // ---- W1, W2 slices -> registers; W3, biases, LayerNorm vectors -> LDS; once ----
@@ -657,8 +660,10 @@ __device__ __forceinline__ float row_all16(float v) {
 // RECOMP: A.d2 / A.d1 hold u = dropout(z) of the hidden layers (forward mode 2); the derivative factors are
 // re-evaluated here from u and the regenerated dropout masks
 template <bool RECOMP>
-__global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A) {
+__global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A0) {
   __shared__ __attribute__((aligned(16))) char smem[FB_LDS];
+  FF3B A = A0;                                                  // (the masks' device-side counter folded into the seeds)
+  A.drop2 = drop_resolve(A0.drop2); A.drop0 = drop_resolve(A0.drop0); A.drop1 = drop_resolve(A0.drop1);
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, li = l & 15;
   f16x8 w3h[2][2], w2h[2][8], w2l[2][8];
   {
@@ -1029,7 +1034,7 @@ int ff3_fused_fwd(const rpde_ff_params* p, const float* x, const float* residual
     uint64_t z = p->seed + 0x9E3779B97F4A7C15ull * (uint64_t)(l + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    A.drop[l] = make_drop(p->dropout_p, z ^ (z >> 31));
+    A.drop[l] = make_drop(p->dropout_p, z ^ (z >> 31), p->seed_epoch);
   }
   A.ntiles = (int)((P + 31) / 32);
   int dev = 0, cus = 256;
@@ -1064,7 +1069,7 @@ int ff3_fused_bwd_launch(const rpde_ff_params* p, const float* const* ds, int re
     uint64_t z = p->seed + 0x9E3779B97F4A7C15ull * (uint64_t)(l + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    dc[l] = make_drop(p->dropout_p, z ^ (z >> 31));
+    dc[l] = make_drop(p->dropout_p, z ^ (z >> 31), p->seed_epoch);
   }
   A.drop0 = dc[0]; A.drop1 = dc[1]; A.drop2 = dc[2];
   A.dmax = 1.13f * A.drop2.scale;          // |gelu'| <= 1.129, times the dropout scale folded into d

@@ -189,6 +189,7 @@ __device__ __forceinline__ void bimg_store(char* __restrict__ lds, const u32x4 (
 // K may have a tail (the images are zero-padded to a multiple of 32) as long as B is x-major.
 template <int WM, int WN, int TM, int TN, bool AK, bool BKM, bool BIMG = false, bool AIMG = false>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x3_kernel(const GemmK g) {
+  const DropCfg gdrop = drop_resolve(g.drop);      // (device-side mask counter folded in: rpde_internal.h)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int NT = 64 * WM * WN;          // 4 waves (3 workgroups per CU) or 8 waves (2 per CU = 4 waves per SIMD)
   static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x
   STAMP_RT(25);   // (overwrites k7's last stamp: constant-rate clock at loop end, for the shader frequency)
 
   // ---- epilogue (same as the fp32 kernel's vector path; the host only dispatches here when g.cvec) ----
-  const bool drop_e = g.drop.on() && (g.drop_where & 4);
+  const bool drop_e = gdrop.on() && (g.drop_where & 4);
   float* __restrict__ cs = reinterpret_cast<float*>(smem_raw);
   constexpr int SLAB = BM / EP;
   constexpr int VPR = BN / 4;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x
           if (gm0 + it * RSTEP >= g.M) break;
           const float4 t = *reinterpret_cast<const float4*>(cs + (row0 + it * RSTEP) * BN + c4);
           float s[4] = {1.f, 1.f, 1.f, 1.f};
-          if (drop_e) drop_scale4(g.drop, did, s);
+          if (drop_e) drop_scale4(gdrop, did, s);
           const float u0 = fmaf(t.x, g.alpha, bn4.x) * s[0], u1 = fmaf(t.y, g.alpha, bn4.y) * s[1];
           const float u2 = fmaf(t.z, g.alpha, bn4.z) * s[2], u3 = fmaf(t.w, g.alpha, bn4.w) * s[3];
           // (scalar on purpose: a packed-fp32 version, 11 instead of 20 issues per element, measured 0.5 % slower
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x
             v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
           } else if (g.epi_dact) {
             float s[4] = {1.f, 1.f, 1.f, 1.f};
-            if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+            if (drop_e) drop_scale4(gdrop, (uint64_t)((long)gm * g.drop_ld + gn), s);
             const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
             v.x *= dact_f(g.epi_dact, a.x * s[0]) * s[0];
             v.y *= dact_f(g.epi_dact, a.y * s[1]) * s[1];
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : 3) void gemm_bf16x
           }
           if (g.write_act) {
             float s[4] = {1.f, 1.f, 1.f, 1.f};
-            if (drop_e && !g.epi_dact) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+            if (drop_e && !g.epi_dact) drop_scale4(gdrop, (uint64_t)((long)gm * g.drop_ld + gn), s);
             v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
             if (g.aux_out) {
               float4 dv;

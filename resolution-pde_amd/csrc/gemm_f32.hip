@@ -35,7 +35,7 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t st) {
   g.bias = d.bias; g.bias_mode = d.bias ? d.bias_mode : 0;
   g.act_a = d.act_a; g.act_b = d.act_b; g.epi_dact = d.epi_dact; g.write_act = d.write_act;
   g.aux = d.aux; g.ldaux = d.ldaux;
-  g.drop = make_drop(d.drop_p, d.drop_seed); g.drop_ld = d.drop_ld; g.drop_where = d.drop_where;
+  g.drop = make_drop(d.drop_p, d.drop_seed, d.drop_epoch); g.drop_ld = d.drop_ld; g.drop_where = d.drop_where;
   const int pro = d.act_a ? 1 : ((d.act_b || (g.drop.on() && (d.drop_where & 2))) ? 2 : ((g.drop.on() && (d.drop_where & 1)) ? 1 : 0));
 
   // 16-byte vector path: aligned bases / strides / leading dims, and the extent

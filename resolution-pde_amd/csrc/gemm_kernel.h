@@ -194,6 +194,7 @@ __device__ __forceinline__ bool tile_coords(const GemmK& g, int& mt, int& nt, in
 template <int WM, int WN, int TM, int TN, bool AK, bool BKM, int PRO, bool VEC, int BK = 32, int STAGES = 2, bool PIPE = false,
           bool PREAUX = false>
 __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(const GemmK g) {
+  const DropCfg gdrop = drop_resolve(g.drop);      // (device-side mask counter folded in: rpde_internal.h)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
   using TA = Tile<BM, BK, AK, VEC, PRO == 1>;
@@ -258,17 +259,17 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
       }
   }
 
-  const bool drop_a = g.drop.on() && (g.drop_where & 1);
-  const bool drop_b = g.drop.on() && (g.drop_where & 2);
-  const bool drop_e = g.drop.on() && (g.drop_where & 4);
+  const bool drop_a = gdrop.on() && (g.drop_where & 1);
+  const bool drop_b = gdrop.on() && (g.drop_where & 2);
+  const bool drop_e = gdrop.on() && (g.drop_where & 4);
   // ---- main loop (PIPE = false): register prefetch one tile ahead, stage after the MFMA block ----
   if constexpr (!PIPE) {
     float4 ra[TA::NV], rb[TB::NV];
     if (nkt > 0) {
       TA::load(ra, A, g.lda, m0, g.M, kbeg, kend, tid);
       TB::load(rb, B, g.ldb, n0, g.N, kbeg, kend, tid);
-      TA::store(As0, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, kbeg);
-      TB::store(Bs0, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, kbeg);
+      TA::store(As0, ra, tid, g.act_a, drop_a, gdrop, g.drop_ld, m0, kbeg);
+      TB::store(Bs0, rb, tid, g.act_b, drop_b, gdrop, g.drop_ld, n0, kbeg);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -297,8 +298,8 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
       }
       if (STAGES == 1) __syncthreads();
       if (more) {
-        TA::store((kt & 1) ? As0 : As1, ra, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);
-        TB::store((kt & 1) ? Bs0 : Bs1, rb, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext);
+        TA::store((kt & 1) ? As0 : As1, ra, tid, g.act_a, drop_a, gdrop, g.drop_ld, m0, knext);
+        TB::store((kt & 1) ? Bs0 : Bs1, rb, tid, g.act_b, drop_b, gdrop, g.drop_ld, n0, knext);
       }
       __syncthreads();
     }
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
     TB::load(rb0, B, g.ldb, n0, g.N, kbeg, kend, tid);
     TA::load(ra1, A, g.lda, m0, g.M, kbeg + BK, kend, tid);
     TB::load(rb1, B, g.ldb, n0, g.N, kbeg + BK, kend, tid);
-    TA::store(As0, ra0, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, kbeg);
-    TB::store(Bs0, rb0, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, kbeg);
+    TA::store(As0, ra0, tid, g.act_a, drop_a, gdrop, g.drop_ld, m0, kbeg);
+    TB::store(Bs0, rb0, tid, g.act_b, drop_b, gdrop, g.drop_ld, n0, kbeg);
   }
   __syncthreads();
 
@@ -336,21 +337,21 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
           _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                            \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);               \
       if (STAGES == 2 && more) {                                                                                    \
-        if (q == 0) { TA::template store<0, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);   \
-                      TB::template store<0, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext); } \
-        if (q == 1) { TA::template store<1, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);   \
-                      TB::template store<1, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext); } \
-        if (NQ > 2 && q == 2) { TA::template store<2 % NQ, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);   \
-                      TB::template store<2 % NQ, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext); } \
-        if (NQ > 3 && q == 3) { TA::template store<3 % NQ, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);   \
-                      TB::template store<3 % NQ, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext); } \
+        if (q == 0) { TA::template store<0, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, gdrop, g.drop_ld, m0, knext);   \
+                      TB::template store<0, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, gdrop, g.drop_ld, n0, knext); } \
+        if (q == 1) { TA::template store<1, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, gdrop, g.drop_ld, m0, knext);   \
+                      TB::template store<1, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, gdrop, g.drop_ld, n0, knext); } \
+        if (NQ > 2 && q == 2) { TA::template store<2 % NQ, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, gdrop, g.drop_ld, m0, knext);   \
+                      TB::template store<2 % NQ, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, gdrop, g.drop_ld, n0, knext); } \
+        if (NQ > 3 && q == 3) { TA::template store<3 % NQ, NQ>(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, gdrop, g.drop_ld, m0, knext);   \
+                      TB::template store<3 % NQ, NQ>(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, gdrop, g.drop_ld, n0, knext); } \
       }                                                                                                             \
     }                                                                                                               \
     if (STAGES == 1) {                                                                                              \
       __syncthreads();                                                                                              \
       if (more) {                                                                                                   \
-        TA::store(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, g.drop, g.drop_ld, m0, knext);                            \
-        TB::store(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, g.drop, g.drop_ld, n0, knext);                            \
+        TA::store(AS_NEXT, RA_NEXT, tid, g.act_a, drop_a, gdrop, g.drop_ld, m0, knext);                            \
+        TB::store(BS_NEXT, RB_NEXT, tid, g.act_b, drop_b, gdrop, g.drop_ld, n0, knext);                            \
       }                                                                                                             \
     }                                                                                                               \
     __syncthreads();                                                                                                \
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
             v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
           } else if (g.epi_dact) {
             float s[4] = {1.f, 1.f, 1.f, 1.f};
-            if (drop_e) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+            if (drop_e) drop_scale4(gdrop, (uint64_t)((long)gm * g.drop_ld + gn), s);
             const float4 a = *reinterpret_cast<const float4*>(aux + (long)gm * g.ldaux + gn);
             v.x *= dact_f(g.epi_dact, a.x * s[0]) * s[0];
             v.y *= dact_f(g.epi_dact, a.y * s[1]) * s[1];
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
           }
           if (g.write_act) {
             float s[4] = {1.f, 1.f, 1.f, 1.f};
-            if (drop_e && !g.epi_dact) drop_scale4(g.drop, (uint64_t)((long)gm * g.drop_ld + gn), s);
+            if (drop_e && !g.epi_dact) drop_scale4(gdrop, (uint64_t)((long)gm * g.drop_ld + gn), s);
             v.x *= s[0]; v.y *= s[1]; v.z *= s[2]; v.w *= s[3];
             if (g.aux_out) {
               float4 dv;
@@ -488,14 +489,14 @@ __global__ __launch_bounds__(NTHREADS, PREAUX ? 3 : 1) void gemm_f32_kernel(cons
             v *= ab[dm * g.ldaux];
           } else if (g.epi_dact) {
             float s = 1.f;
-            if (drop_e) s = drop_scale1(g.drop, idb + (uint64_t)(dm * g.drop_ld));
+            if (drop_e) s = drop_scale1(gdrop, idb + (uint64_t)(dm * g.drop_ld));
             const float u = ab[dm * g.ldaux] * s;
             v = v * dact_f(g.epi_dact, u) * s;
           }
           if (g.accumulate) v += g.acc_src ? g.acc_src[coff + (long)(mb + dm) * ldc + n] : cb[dm * ldc];
           if (g.write_act) {
             float s = 1.f;
-            if (drop_e && !g.epi_dact) s = drop_scale1(g.drop, idb + (uint64_t)(dm * g.drop_ld));
+            if (drop_e && !g.epi_dact) s = drop_scale1(gdrop, idb + (uint64_t)(dm * g.drop_ld));
             v *= s;
             if (g.aux_out) g.aux_out[coff + (long)(mb + dm) * ldc + n] = dact_f(g.write_act, v) * s;
             v = act_f(g.write_act, v);

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void k_ff_tail_fwd(const float* __restrict__ z
                                                      float* __restrict__ out, long P, int layer_norm, float eps,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      DropCfg drop, int post_act) {
+  drop = drop_resolve(drop);
   constexpr int C = 4 * G;
   const int lane_in_row = threadIdx.x % G;
   const long rows_per_block = 256 / G;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256) void k_ff_tail_fwd_any(const float* __restrict
                                                          float* __restrict__ out, long P, int C, int layer_norm, float eps,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          DropCfg drop, int post_act) {
+  drop = drop_resolve(drop);
   const int lane = threadIdx.x & 63;
   for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < P; row += (long)gridDim.x * 4) {
     float v[8];
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(256) void k_ff_tail_bwd(const float* __restrict__ z
                                                      float* __restrict__ dz, float* __restrict__ slab, long P, int C,
                                                      int layer_norm, float eps, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, DropCfg drop, int post_act) {
+  drop = drop_resolve(drop);
   __shared__ float red[4][2][512];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float dg[8], db[8];
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256) void k_ff_tail_bwd_vec(const float* __restrict
                                                          float* __restrict__ dz, float* __restrict__ slab, long P,
                                                          int layer_norm, float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, DropCfg drop, int post_act) {
+  drop = drop_resolve(drop);
   constexpr int C = 4 * G;
   constexpr int RPB = 256 / G;
   __shared__ float red[3][RPB][C];

@@ -116,17 +116,30 @@ struct DropCfg {
   uint64_t seed;
   uint32_t thresh;   // drop when 16-bit uniform < thresh
   float scale;       // 1/(1-p)
+  // optional device counter mixed into the seed by the KERNEL (drop_resolve): a captured hipGraph replays its launch
+  // arguments, so a seed drawn on the host would freeze the masks -- the training step advances this counter on the
+  // device instead (rpde.ops.drop_epoch, rpde/graph.py); forward and backward of one step see the same value
+  const uint64_t* epoch;
   __host__ __device__ bool on() const { return thresh != 0; }
 };
-inline DropCfg make_drop(float p, uint64_t seed) {
+inline DropCfg make_drop(float p, uint64_t seed, const uint64_t* epoch = nullptr) {
   DropCfg d;
   d.seed = seed;
-  if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; return d; }
+  d.epoch = epoch;
+  if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; d.epoch = nullptr; return d; }
   double t = (double)p * 65536.0;
   d.thresh = (uint32_t)(t + 0.5);
   if (d.thresh > 65535u) d.thresh = 65535u;
   if (d.thresh == 0) d.thresh = 1;
   d.scale = (float)(1.0 / (1.0 - (double)d.thresh / 65536.0));
+  return d;
+}
+// once per kernel, before the first mask: the configuration with the device counter folded into the seed
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg d) {
+  if (d.epoch) {
+    d.seed ^= (*d.epoch) * 0x9E3779B97F4A7C15ull;
+    d.epoch = nullptr;
+  }
   return d;
 }
 __device__ __forceinline__ uint32_t drop_base(const DropCfg& d, uint64_t group) {

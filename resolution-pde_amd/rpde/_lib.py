@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_ld", C.c_int64),
         ("write_act", C.c_int), ("drop_where", C.c_int),
         ("colsum", C.c_void_p), ("aux_out", C.c_void_p), ("b_split", C.c_void_p), ("a_split", C.c_void_p), ("acc_src", C.c_void_p),
+        ("drop_epoch", C.c_void_p),
     ]
 
 
@@ -56,6 +57,7 @@ class FFParams(C.Structure):
         ("post_act", C.c_int),
         ("weights", C.POINTER(C.c_void_p)), ("biases", C.POINTER(C.c_void_p)),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+        ("seed_epoch", C.c_void_p),
     ]
 
 

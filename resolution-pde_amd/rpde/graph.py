@@ -9,8 +9,15 @@ enough that host launches show: FNO1d 1024, B=16: 1.05 ms eager vs 0.72 ms repla
 Everything the step does already is stream-ordered and allocation-free at the HIP level (workspaces come
 from torch's caching allocator, DFT plans are created on first use), so the capture needs no changes in the
 library -- only: plans and autotuned state must exist before capture (warm-up steps), the optimizer must be
-capturable, and nothing in the step may read a host-side random seed: FeedForward dropout draws its seed on
-the host, so a model with dropout > 0 in training mode is refused here (its mask would freeze).
+capturable, and nothing in the step may depend on a host-side random draw.  FeedForward dropout draws its seed
+on the host, which a replay would repeat; the dropout kernels therefore also mix a DEVICE counter into the seed
+(rpde.ops.drop_epoch, rpde_ff_params.seed_epoch) and the captured step advances it first thing, so every
+replay draws new masks and forward / backward of one step agree.  torch.nn.Dropout modules (none in the FNO /
+FFNO families) would still freeze and are refused.
+
+Round 4: the headline step (FFNO2D cfg3, dropout 0.1, B = 32, 256^2: ~250 launches per 31 ms) captured together
+with FlatGradBucket.all_reduce_mean -- bench.py reports eager vs replayed; with 8 ranks on one host the launches
+of a step are issued by 8 processes, which is the case the graph is for.
 """
 from __future__ import annotations
 
@@ -19,14 +26,15 @@ from typing import Callable, Optional
 import torch
 
 
-def _has_active_dropout(model: torch.nn.Module) -> bool:
+def _has_torch_dropout(model: torch.nn.Module) -> bool:
+    """a torch.nn.Dropout that would really run (the FeedForward keeps nn.Dropout children for the state_dict layout
+    only: its masks come from the fused kernels)"""
+    from models.custom_layer import FeedForward
+    owned = set()
     for m in model.modules():
-        p = getattr(m, "dropout", None)
-        if isinstance(p, float) and p > 0.0 and m.training:
-            return True
-        if isinstance(m, torch.nn.Dropout) and m.p > 0.0 and m.training:
-            return True
-    return False
+        if isinstance(m, FeedForward):
+            owned.update(id(c) for c in m.modules())
+    return any(isinstance(m, torch.nn.Dropout) and m.p > 0.0 and m.training and id(m) not in owned for m in model.modules())
 
 
 class GraphedTrainStep:
@@ -40,8 +48,8 @@ class GraphedTrainStep:
                  after_backward: Optional[Callable[[], None]] = None):
         if not x.is_cuda:
             raise ValueError("GraphedTrainStep needs HIP tensors")
-        if _has_active_dropout(model):
-            raise ValueError("GraphedTrainStep: dropout > 0 in training mode draws a host-side seed per step; "
+        if _has_torch_dropout(model):
+            raise ValueError("GraphedTrainStep: a torch.nn.Dropout in training mode draws from the host-side generator; "
                              "a captured graph would replay one mask.  Use eager steps for this model.")
         for group in optimizer.param_groups:
             if "capturable" in group and not group["capturable"]:
@@ -66,6 +74,8 @@ class GraphedTrainStep:
         return [(float(g.get("lr", 0.0)), float(g.get("weight_decay", 0.0))) for g in self.optimizer.param_groups]
 
     def _eager(self) -> torch.Tensor:
+        from . import ops
+        ops.drop_epoch(self.x.device).add_(1)        # new dropout masks at every replay (device-side counter)
         self.optimizer.zero_grad(set_to_none=False)
         loss = self.loss_fn(self.model(self.x), self.y)
         loss.backward()

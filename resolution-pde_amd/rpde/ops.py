@@ -220,6 +220,26 @@ def fspectral2d(x, wy, wx, modes: int, mode: str = "full", with_skip: bool = Fal
 
 
 # ----------------------------------------------------------------------------
+# dropout masks under a captured hipGraph: a replay repeats its launch arguments, so the seed the FeedForward draws on
+# the host would freeze one mask for ever.  Every dropout kernel therefore also mixes a DEVICE counter into its seed
+# (rpde_ff_params.seed_epoch); eager steps leave it at 0 (the host seed changes per call), a GraphedTrainStep advances it
+# once per replay -- on the device, inside the graph -- before the forward, so forward and backward of one step agree.
+# ----------------------------------------------------------------------------
+_DROP_EPOCH: dict = {}
+
+
+def drop_epoch(device) -> torch.Tensor:
+    """the int64 [1] device counter of `device` (created on first use, 0)"""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _DROP_EPOCH.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=dev)
+        _DROP_EPOCH[key] = t
+    return t
+
+
+# ----------------------------------------------------------------------------
 # FeedForward (+ residual / post-activation glue)
 # ----------------------------------------------------------------------------
 class _FeedForward(torch.autograd.Function):
@@ -256,8 +276,9 @@ class _FeedForward(torch.autograd.Function):
         # (the pre-LayerNorm tensor is saved for backward only: the evaluation kernel does not write it)
         z_last = out if lean else torch.empty(P, dim, dtype=torch.float32, device=x.device)
         wa, ba, ha, da = ptr_array(ws_), ptr_array(bs_), ptr_array(hs or [None]), ptr_array(ds or [None])
+        epoch = drop_epoch(x.device).data_ptr() if p_drop > 0.0 else None
         fp = _lib.FFParams(L, dim, factor, int(layer_norm), eps, p_drop, seed, post_act,
-                           C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta))
+                           C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta), epoch)
         nws = lib.rpde_feedforward_fwd_ws_bytes(dim, factor, L)
         if lean and p_drop == 0.0:
             held = tuple(ws_ + bs_ + ([gamma, beta] if layer_norm else []))
@@ -300,8 +321,9 @@ class _FeedForward(torch.autograd.Function):
         gbeta = torch.empty_like(beta) if layer_norm else None
         wa, ba, ha, da = ptr_array(ws_), ptr_array(bs_), ptr_array(hs or [None]), ptr_array(ds or [None])
         gwa, gba = ptr_array(gws), ptr_array(gbs)
+        epoch = drop_epoch(g.device).data_ptr() if p_drop > 0.0 else None
         fp = _lib.FFParams(L, dim, factor, int(layer_norm), eps, p_drop, seed, post_act,
-                           C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta))
+                           C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p)), ptr(gamma), ptr(beta), epoch)
         nws = lib.rpde_feedforward_ws_bytes(P, dim, factor, L)
         ws = workspace(nws, g.device)
         check(lib.rpde_feedforward_bwd(C.byref(fp), ptr(x2), C.cast(ha, C.POINTER(C.c_void_p)),

@@ -75,15 +75,22 @@ class ResolutionGroupedSampler(Sampler):
 
 class ResolutionGroupedDataLoader:
     def __init__(self, dataset, batch_size, shuffle=True, num_workers=0, seed: Optional[int] = None,
-                 rank: int = 0, world_size: int = 1, verbose: bool = True, drop_last: Optional[bool] = None):
+                 rank: int = 0, world_size: int = 1, verbose: bool = True, drop_last: Optional[bool] = None,
+                 pin_memory: bool = False):
         """drop_last (world_size > 1 only; default = ``shuffle``): True for training -- equal rank slices of whole
         global batches, so that every rank runs the same shapes in the same order beside the gradient all-reduce;
         False for validation / test -- every sample is used exactly once: rank r takes samples r, r+world, ... of
-        each resolution and keeps its ragged (possibly empty) tail; the caller reduces a sample-weighted sum"""
+        each resolution and keeps its ragged (possibly empty) tail; the caller reduces a sample-weighted sum.
+        pin_memory: batches are stacked into page-locked staging buffers (two per resolution and tensor, used in
+        turn), so that ``batch.to(device, non_blocking=True)`` is an asynchronous copy; a batch is valid until the
+        second-next batch of the same resolution is drawn"""
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
         self.drop_last = bool(shuffle) if drop_last is None else bool(drop_last)
         self.seed, self.rank, self.world_size = seed, int(rank), int(world_size)
         self.epoch = 0
+        self.pin_memory = bool(pin_memory) and torch.cuda.is_available()
+        self._pinned: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._turn: Dict[int, int] = defaultdict(int)
         if not 0 <= self.rank < self.world_size:
             raise ValueError(f"rank {rank} outside world of {world_size}")
         self.resolution_groups: Dict[int, List[Tuple[torch.Tensor, torch.Tensor]]] = defaultdict(list)
@@ -125,7 +132,21 @@ class ResolutionGroupedDataLoader:
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         for res, idxs in self._plan():
             samples = self.resolution_groups[res]
-            yield (torch.stack([samples[i][0] for i in idxs]), torch.stack([samples[i][1] for i in idxs]))
+            if not self.pin_memory:
+                yield (torch.stack([samples[i][0] for i in idxs]), torch.stack([samples[i][1] for i in idxs]))
+                continue
+            turn = self._turn[res]
+            self._turn[res] = turn ^ 1
+            out = []
+            for which in (0, 1):
+                parts = [samples[i][which] for i in idxs]
+                key = (res, which, turn)
+                buf = self._pinned.get(key)
+                if buf is None or buf.shape[0] < len(parts) or buf.shape[1:] != parts[0].shape or buf.dtype != parts[0].dtype:
+                    buf = torch.empty((self.batch_size,) + tuple(parts[0].shape), dtype=parts[0].dtype).pin_memory()
+                    self._pinned[key] = buf
+                out.append(torch.stack(parts, out=buf[:len(parts)]))
+            yield tuple(out)
         self.epoch += 1
 
     def __len__(self):

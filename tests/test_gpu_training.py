@@ -227,11 +227,84 @@ def test_graphed_train_step_matches_eager(gpu_device):
     for pe, pg in zip(m_e.parameters(), m_g.parameters()):
         a, b = torch.view_as_real(pe) if pe.is_complex() else pe, torch.view_as_real(pg) if pg.is_complex() else pg
         assert float((a - b).norm() / (a.norm() + 1e-30)) < 1e-6
-    from models.ffno import FFNO2D
-    with pytest.raises(ValueError, match="dropout"):
-        md = FFNO2D(1, 1, width=8, n_layers=1, n_modes=4, dropout=0.1).to(gpu_device).train()
+    # a torch.nn.Dropout draws from the host generator: a replay would repeat one mask -> refused
+    class WithTorchDropout(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.drop, self.net = torch.nn.Dropout(0.1), FNO1d(1, 1, modes=4, width=8)
+
+        def forward(self, x):
+            return self.net(self.drop(x))
+    with pytest.raises(ValueError, match="Dropout"):
+        md = WithTorchDropout().to(gpu_device).train()
         GraphedTrainStep(md, loss_fn, torch.optim.AdamW(md.parameters(), capturable=True),
-                         torch.randn(2, 1, 16, 16, device=gpu_device), torch.randn(2, 1, 16, 16, device=gpu_device))
+                         torch.randn(2, 1, 64, device=gpu_device), torch.randn(2, 1, 64, device=gpu_device))
+
+
+@pytest.mark.parametrize("dim,factor", [(64, 4), (32, 2)])          # the fused kernels / the per-GEMM path
+def test_dropout_device_epoch_changes_masks_and_keeps_backward_in_step(gpu_device, dim, factor):
+    """rpde_ff_params.seed_epoch: the device counter every dropout kernel mixes into its seed (what lets a captured
+    hipGraph draw new masks per replay).  Same host seed: equal counter -> equal bits, other counter -> other masks with
+    the same drop rate; and at a non-zero counter the backward still regenerates the forward's masks (directional
+    finite difference)."""
+    from models.custom_layer import FeedForward
+    from rpde import ops
+    torch.manual_seed(2)
+    ff = FeedForward(dim, factor, n_layers=3, layer_norm=False, dropout=0.25).to(gpu_device).train()
+    x = torch.randn(4096, dim, device=gpu_device)
+    ep = ops.drop_epoch(gpu_device)
+
+    def run(epoch, xx=x):
+        ep.fill_(epoch)
+        torch.manual_seed(77)                            # the same host-side seed draw every time
+        return ff(xx)
+    try:
+        with torch.no_grad():
+            a0, a0b, a1 = run(0), run(0), run(1)
+        assert torch.equal(a0, a0b)
+        assert not torch.equal(a0, a1)
+        for a in (a0, a1):                               # last layer: out = dropout(z3): a fraction p is exactly zero
+            assert abs(float((a == 0).float().mean()) - 0.25) < 0.02
+        assert float(((a0 == 0) & (a1 == 0)).float().mean()) < 0.12        # independent masks overlap in ~p^2 = 6 %
+        cot = torch.randn_like(x)
+        v = torch.randn_like(x)
+        v /= v.norm()
+        xr = x.clone().requires_grad_(True)
+        (run(7, xr) * cot).sum().backward()
+        analytic = float((xr.grad * v).sum())
+        eps = 2e-2
+        with torch.no_grad():
+            numeric = float(((run(7, x + eps * v) * cot).sum().double() - (run(7, x - eps * v) * cot).sum().double()) / (2 * eps))
+        assert abs(analytic - numeric) <= 3e-2 * max(1.0, abs(numeric)), (analytic, numeric)
+    finally:
+        ep.zero_()
+
+
+def test_graphed_headline_shape_step_draws_new_masks_per_replay(gpu_device):
+    """GraphedTrainStep on a model WITH FeedForward dropout (the headline layer shape, small grid): the captured step
+    advances the device-side mask counter, so two replays on the same batch see different masks (different losses)
+    while an evaluation forward stays deterministic; weights stay finite and the loss goes down over a few replays."""
+    from models.ffno import FFNO2D
+    from rpde import ops
+    from rpde.graph import GraphedTrainStep
+    from rpde.optim import FlatAdamW
+    from utils.loss import RelativeL2Loss
+    from utils.synthetic import advance, random_fields
+    torch.manual_seed(0)
+    m = FFNO2D(1, 1, width=64, n_layers=2, n_modes=12, factor=4, ff_weight_norm=True, n_ff_layers=3, layer_norm=True,
+               dropout=0.2).to(gpu_device).train()
+    opt = FlatAdamW(m.parameters(), lr=1e-3, capturable=True)
+    x = random_fields(4, 32, 2, seed=3)
+    y = advance(x, 2).to(gpu_device)
+    x = x.to(gpu_device)
+    e0 = int(ops.drop_epoch(gpu_device).item())
+    step = GraphedTrainStep(m, RelativeL2Loss(), opt, x, y, warmup=2)
+    losses = [float(step(x, y)) for _ in range(12)]
+    assert int(ops.drop_epoch(gpu_device).item()) == e0 + 2 + 12           # warm-up steps + replays (capture runs nothing)
+    assert len({round(v, 7) for v in losses}) > 8, losses                     # not one frozen mask
+    assert all(torch.isfinite(p_).all() for p_ in m.parameters())
+    assert min(losses[-3:]) < losses[0]
+    ops.drop_epoch(gpu_device).zero_()
 
 
 def test_main_2d_on_a_file_dataset_with_normalisers(gpu_device, tmp_path, capsys):
