@@ -278,6 +278,15 @@ int rpde_fnoblock2d_eval_ok(int Cin, int Cout, int M, int N, int m2);
 int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc, float* out,
                              int B, int Cin, int Cout, int M, int N, int m1, int m2, int act_out,
                              void* ws, size_t ws_bytes, void* stream);
+/* the LAST block of an FNO2d and its projection MLP in evaluation, one entry point (reference models/fno.py:143-150:
+ * fno_blocks[-1] -> projection = mlp2(gelu(mlp1(.)))): out [B,Cq,M,N] = pw2 . gelu(pw1 . act_out(SpectralConv2d(x) +
+ * Conv2d_1x1(x)) + pb1) + pb2 with pw1 [Cmid,Cout], pw2 [Cq,Cmid].  The block's output never reaches HBM.  Workspace:
+ * rpde_fnoblock2d_eval_ws_bytes.  _ok: Cin = 32, Cout <= 32, Cmid <= 128, Cq <= 4, N % 16 == 0, N <= 1024, m2 <= 16. */
+int rpde_fnoblock2d_proj_eval_ok(int Cin, int Cout, int M, int N, int m1, int m2, int Cmid, int Cq);
+int rpde_fnoblock2d_proj_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc,
+                                  const float* pw1, const float* pb1, const float* pw2, const float* pb2, float* out, int B,
+                                  int Cin, int Cout, int M, int N, int m1, int m2, int act_out, int Cmid, int Cq,
+                                  void* ws, size_t ws_bytes, void* stream);
 /* FNO2d.forward in evaluation, up to and including the first block (reference models/fno.py:121-147:
  * cat(x, gridx, gridy) -> lifting -> fno_blocks[0]), without the lifted field ever being written or read:
  * u [B,1,M,N], gx [M], gy [N] (the grid coordinates, device arrays), wl [C,3], bl [C] (lifting conv), then the block's

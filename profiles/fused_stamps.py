@@ -24,7 +24,10 @@ buf = (C.c_ulonglong * (2 * 64 * 32))()
 lib.rpde_debug_fused_stamps.argtypes = [C.c_void_p]
 _lib.check(lib.rpde_debug_fused_stamps(buf), "stamps")
 t = np.array(buf, dtype=np.uint64).reshape(2, 64, 32).astype(np.int64)
-for k, name in ((0, "analysis_sq, units 9..11 of one wave: [top, y landed, y done, B1 passed, partials written, B2 passed, "
+rr = os.environ.get("RPDE_ANA_RR", "1") != "0"
+for k, name in ((0, "analysis_rr, rounds 9..12 of one wave: [top, barrier passed, first landed, first processed, (issue +) second landed, "
+                    "second processed, second issued] x 4" if rr else
+                    "analysis_sq, units 9..11 of one wave: [top, y landed, y done, B1 passed, partials written, B2 passed, "
                     "reduced+stored, B3 passed, x landed, x done] x 3"), (1, "synthesis")):
     a = t[k]
     a = a[a[:, 0] > 0]

@@ -20,4 +20,11 @@ bool conv_syn_h2_ok(const float* x, const float* out, const float* t, int Cin, i
 int conv_syn_h2(const float* x, const float* w, const float* bias, const float* t, const float* fs_t, float* out, int B, int Cin,
                 int Cout, int M, int N, int R2, int act_out, hipStream_t st, const float* lift_u = nullptr,
                 const float* lift_w = nullptr, const float* lift_b = nullptr, const float* gx = nullptr, const float* gy = nullptr);
+
+// last block's tail + projection MLP in one pass (conv_proj_h2.hip): out [B,Cq,M,N]
+bool conv_syn_proj_ok(int Cin, int Cout, int M, int N, int R2, int Cmid, int Cq);
+int conv_syn_proj(const float* x, const float* wc, const float* bc, const float* t, const float* fs_t, const float* w1,
+                  const float* b1, const float* w2, const float* b2, float* out, int B, int Cout, int M, int N, int R2, int Cmid,
+                  int Cq, int act, hipStream_t st);
+
 }  // namespace rpde

@@ -651,6 +651,211 @@ __global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_sq_h2(const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// analysis of square grids, one pass over HBM and NO cross-wave reduction: the round-robin schedule (round 4)
+// ------------------------------------------------------------------------------------------------------------
+// k_dft_analysis_sq_h2 reads the field once, but a row's eight 32-point chunks sit in eight waves and their partial
+// spectra are summed through 96 KB of LDS behind two barriers per step -- in-kernel stamps put 5.8 K of a step's 12.3 K
+// cycles there, against 4.3 K for the chunks themselves.  The sum exists because in a 32-row block every wave has one
+// chunk of a column (32 rows) but only an eighth of a row.  It goes away if a wave meets its WHOLE row over the rounds of
+// a sample the way it already meets its whole column: cut the sample into nb x nb tiles of 32 x 32 points (nb = n / 32)
+// and let wave gw of a group own row gw AND column gw.  In round t the wave in band i = gw / 32 adds
+//   * to its row accumulators    the 32 points of its row    that lie in tile (i, i + t),      and
+//   * to its column accumulators the 32 points of its column that lie in tile (i - t, i)       (indices mod nb).
+// Tile (a, b) is then read in round b - a by the waves of band a (as rows) and by the waves of band b (as columns): both
+// in the SAME round -- a tournament schedule -- so the second read finds the tile in the L2 of the XCD that the group's
+// workgroups share (placement is a speed matter only), exactly the 2 MB per round that the row-block walk keeps there.
+// After nb rounds every wave holds one finished row spectrum and one finished column spectrum.  No landing zone, no
+// partial sums, no barrier after the table is in LDS; the table (48 KB) is all the LDS the kernel uses; every wave has a
+// row and a column on every grid (a group is exactly n waves = n / 8 workgroups), so the idle-wave cases of the
+// row-block kernel (and the memory fault they once caused) do not exist here.
+// Loads: inline asm one round ahead, as there; behind a chunk there are always the 8 loads of the other axis's chunk, so
+// a fixed vmcnt(8) covers it (the 20-odd spectrum stores of a sample's last round only make that wait longer).
+// Measured (profiles/r04_analysis_variants.txt; 256^2, B = 32, same box within a pair; FETCH = 2 x FETCH_SIZE):
+//   row-block kernel k_dft_analysis_sq_h2 ............................ 208 us, 551 MB fetched
+//   this kernel, every wave free-running ............................. 213 us, 847 MB  (waves of a workgroup drift apart:
+//                                                                              the second reader of a tile comes too late)
+//   + odd bands take their row chunk first (RPDE_RR_PARITY) .......... 226 us, 838 MB
+//   + ONE s_barrier per round (RPDE_RR_BARRIER; no LDS traffic) ...... 196 us, 565 MB  <- shipped
+// In-kernel stamps of the shipped form (profiles/fused_stamps.py): of a round's ~13 K cycles the two chunks take 2 x 1.6 K;
+// ISSUING a chunk's eight loads takes 1.5-4 K -- the CU's vector-memory pipeline accepts a 1 KB wave-load every ~100
+// cycles once its queues are full, i.e. ~10 bytes per cycle and CU (the HBM-bound streaming rate of
+// MI355X_MICROARCH.md's cycle table) -- and the barrier absorbs the skew that leaves.  Every byte of the field passes
+// that pipeline TWICE (once per axis; the second time from L2 at about twice the rate): 2.1 MB / 10 + 2.1 MB / 23 +
+// 0.66 MB / 10 bytes per cycle = 0.37 M cycles = 185 us at 2 GHz.  The kernel is at the rate of the bytes its CUs load,
+// not of the bytes HBM delivers; only loading each byte once per CU would change that.
+#ifndef RPDE_RR_PARITY
+#define RPDE_RR_PARITY 1
+#endif
+#ifndef RPDE_RR_BARRIER
+#define RPDE_RR_BARRIER 1
+#endif
+struct AnaRrP {
+  const float* x; const char* timg;
+  float* spec_y; float* spec_x; float* amax_y; float* amax_x;
+  int B, n, nb, R, ng;
+};
+
+template <int MT>
+__global__ __launch_bounds__(64 * ANA_WAVES, 2) void k_dft_analysis_rr_h2(const AnaRrP P) {
+  __shared__ __attribute__((aligned(16))) char smem[ANA_MAXKS * MT * 2048];
+  const int tid = threadIdx.x, l = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = l >> 4, li = l & 15;
+  const int n = P.n, nb = P.nb;
+  const int xg = blockIdx.x % P.ng, jw = blockIdx.x / P.ng, gw = jw * ANA_WAVES + wave;     // gw < n: this wave's row and column
+  const int band = gw >> 5;
+  const int nsamp = (P.B - xg + P.ng - 1) / P.ng;
+  const long units = (long)nsamp * nb;               // (sample, round) pairs of this group, in order
+  if (units <= 0) return;                            // (more groups than samples)
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(P.timg);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = tid; i < nb * MT * 128; i += 64 * ANA_WAVES) dst[i] = src[i];
+    __syncthreads();
+  }
+  const long rowf = (long)n * 64;                    // floats per row of the field
+  auto gload = [](const float* p) {
+    f32x4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  };
+  // Which chunk a wave takes first.  Tile (a, a + t) is read by band a as a ROW chunk and by band a + t as a COLUMN chunk;
+  // the second read finds the tile in L2 more surely when both are requested in the same half of the round than half a
+  // round apart (with "column first" everywhere 58 % of the second reads missed: 847 MB fetched for a 537 MB field).
+  // Odd bands therefore take their row chunk first, even bands their column chunk: every tile of an odd round (a and
+  // a + t of different parity) is then requested by both its readers in the same half.  The order is fixed per wave --
+  // the two accumulator sets are bound to "first" and "second", so nothing in the loop depends on it but addresses.
+  const bool row_first = RPDE_RR_PARITY && (band & 1);
+  // chunk `half` (0: first, 1: second) of round u into buf: a row chunk (points of band (band + t) mod nb, lane (g, li)
+  // takes points 4 i + g, channels 4 li ..) or a column chunk (rows of band (band - t) mod nb).  Past the end: a clamped
+  // re-read, so that every round issues the same 16 loads.  Returns the table chunk that goes with it.
+  auto chunk_of = [&](long u, int half, const float*& q0, long& st) {
+    u = u < units ? u : units - 1;
+    const int sb = (int)(u / nb), t = (int)(u - (long)sb * nb);
+    const bool is_row = row_first == (half == 0);
+    int ra = band - t; ra += ra < 0 ? nb : 0;
+    int cb = band + t; cb -= cb >= nb ? nb : 0;
+    const long base = (long)(xg + P.ng * sb) * n;
+    q0 = is_row ? P.x + ((base + gw) * n + 32 * cb + g) * 64 + li * 4 : P.x + ((base + 32 * ra + g) * n + gw) * 64 + li * 4;
+    st = is_row ? 256 : 4 * rowf;
+    return is_row ? cb : ra;
+  };
+  auto issue = [&](f32x4v (&buf)[8], long u, int half) {
+    const float* q0; long st;
+    chunk_of(u, half, q0, st);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[i] = gload(q0 + i * st);
+  };
+  // the chunk in buf has landed once at most 8 later vector-memory instructions are outstanding: the other axis's chunk
+  // (tests/test_isa_pending_loads_cpu.py follows the `landed` comment, which names the registers)
+  auto landed = [&](f32x4v (&buf)[8]) {
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_nop 0 ; landed %0 %1 %2 %3 %4 %5 %6 %7"
+                 : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]), "+v"(buf[4]), "+v"(buf[5]), "+v"(buf[6]), "+v"(buf[7])
+                 :
+                 : "memory");
+  };
+  // one 32-point chunk into accumulators that stay in scaled units for the whole line (k_dft_analysis_sq_h2's scheme:
+  // running power-of-two scale, no staging -- the loaded registers ARE the B fragments under the permuted table image)
+  auto process = [&](f32x4v (&buf)[8], int s, f32x4v (&tot)[MT][4], int& line_E) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(buf[i].x), fabsf(buf[i].y)), fmaxf(fabsf(buf[i].z), fabsf(buf[i].w))));
+    m = wave_max(m);
+    {
+      const int E = max((int)(__float_as_uint(m) >> 23) & 0xff, 15 + H2_TABLE_EXP);
+      if (E > line_E) {
+        if (line_E > 0) {
+          const float f = __uint_as_float((unsigned)(127 + line_E - E) << 23);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) tot[mt][nt][j] *= (E - line_E < 126 ? f : 0.f);
+        }
+        line_E = E;
+      }
+    }
+    const float scale = __uint_as_float((unsigned)(268 - line_E) << 23);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      union { f16x8 v; struct { uint2 a, b; } u; } H, L;
+      h2_split4(buf[0][e] * scale, buf[1][e] * scale, buf[2][e] * scale, buf[3][e] * scale, H.u.a, L.u.a);
+      h2_split4(buf[4][e] * scale, buf[5][e] * scale, buf[6][e] * scale, buf[7][e] * scale, H.u.b, L.u.b);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const char* ta = smem + (s * MT + mt) * 2048 + l * 16;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(ta), al = *reinterpret_cast<const f16x8*>(ta + 1024);
+        tot[mt][e] = h2_mfma32(ah, al, H.v, L.v, tot[mt][e]);
+      }
+    }
+  };
+  // a finished line: row 16 mt + 4 g + j of the spectrum, channels 4 li .. 4 li + 3 (accumulator column li of tot[mt][e] is
+  // channel 4 li + e), 256 contiguous bytes per 16 lanes; and the line's maximum for the mode mix
+  auto finish = [&](f32x4v (&tot)[MT][4], int line_E, float* __restrict__ spec, float* __restrict__ amax, long z) {
+    float* __restrict__ sp = spec + z * (long)P.R * 64;
+    const float inv = __uint_as_float((unsigned)(line_E - 14 - H2_TABLE_EXP) << 23);
+    float am = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * mt + 4 * g + j;
+        if (row < P.R)
+          *reinterpret_cast<float4*>(sp + row * 64 + 4 * li) =
+              make_float4(tot[mt][0][j] * inv, tot[mt][1][j] * inv, tot[mt][2][j] * inv, tot[mt][3][j] * inv);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) am = fmaxf(am, fabsf(tot[mt][nt][j]));
+      }
+    am = wave_max(am);
+    if (l == 0 && amax) amax[z] = am * inv;
+  };
+
+  f32x4v tota[MT][4], totb[MT][4];                         // the line of the first / the second chunk
+  int Ea = 0, Eb = 0;
+  f32x4v ba[8], bb[8];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the table copy above: from here on the queue is counted by hand)
+  issue(ba, 0, 0);
+  issue(bb, 0, 1);
+  for (long u = 0; u < units; ++u) {
+    const int sb = (int)(u / nb), t = (int)(u - (long)sb * nb);
+    const long z = (long)(xg + P.ng * sb) * n + gw;         // this wave's line of the sample, as a row and as a column
+    if (t == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) tota[mt][nt] = totb[mt][nt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+      Ea = Eb = 0;
+    }
+    const float* q_; long st_;
+    const int sa = chunk_of(u, 0, q_, st_), sbk = chunk_of(u, 1, q_, st_);
+#ifdef RPDE_STAMPS
+    // rounds 9 .. 12 (second sample) of wave 3 of workgroups 96 .. 159: 7 stamps each
+    const bool stamp_on = l == 0 && wave == 3 && blockIdx.x >= 96 && blockIdx.x < 160 && u >= 9 && u < 13;
+    const int stamp_slot = (int)blockIdx.x - 96, sq0 = (int)(u - 9) * 7;
+#endif
+    FSTAMP(0, sq0 + 0);
+    if (RPDE_RR_BARRIER) asm volatile("s_barrier" ::: "memory");      // (keeps the eight waves of a workgroup in one round)
+    FSTAMP(0, sq0 + 1);
+    landed(ba);
+    FSTAMP(0, sq0 + 2);
+    process(ba, sa, tota, Ea);
+    FSTAMP(0, sq0 + 3);
+    issue(ba, u + 1, 0);
+    landed(bb);
+    FSTAMP(0, sq0 + 4);
+    process(bb, sbk, totb, Eb);
+    FSTAMP(0, sq0 + 5);
+    issue(bb, u + 1, 1);
+    FSTAMP(0, sq0 + 6);
+    if (t == nb - 1) {
+      finish(tota, Ea, row_first ? P.spec_y : P.spec_x, row_first ? P.amax_y : P.amax_x, z);
+      finish(totb, Eb, row_first ? P.spec_x : P.spec_y, row_first ? P.amax_x : P.amax_y, z);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the re-reads past the end)
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // split: fp32 spectra [line][R][64] -> operand blocks [line][16-channel block] (layout above) + 1/scale per line
 // ------------------------------------------------------------------------------------------------------------
 template <int K32, int TG>
@@ -1530,12 +1735,35 @@ static bool ana_sq_ok(int M, int N, int cus) {
   return M == N && cus >= 256;
 }
 
+// RPDE_ANA_RR=0: the row-block kernel k_dft_analysis_sq_h2 (cross-wave sums through LDS) instead of the round-robin one
+static bool ana_rr_on() {
+  const char* e = getenv("RPDE_ANA_RR");
+  return !(e && e[0] == '0');
+}
+
 int fused2d_analysis(const float* x, float* spec_y, float* spec_x, float* amax_y, float* amax_x, const rpde_plan* py,
                      const rpde_plan* px, int adjoint, int B, int M, int N, hipStream_t st) {
   {
     int dev = 0, cus = 256;
     RPDE_HIP(hipGetDevice(&dev));
     RPDE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (ana_sq_ok(M, N, cus) && ana_rr_on() && py->h2_ana[adjoint] == px->h2_ana[adjoint]) {
+      // the round-robin schedule: a group = N waves = N / 8 workgroups; as many groups as fit (never more than samples)
+      AnaRrP Q;
+      Q.x = x; Q.timg = (const char*)py->h2_ana_p[adjoint]; Q.spec_y = spec_y; Q.spec_x = spec_x; Q.amax_y = amax_y; Q.amax_x = amax_x;
+      Q.B = B; Q.n = N; Q.nb = N / 32; Q.R = 2 * py->kp;
+      const int wpg = N / ANA_WAVES;
+      int ng = cus / wpg;
+      if (ng < 1) ng = 1;
+      Q.ng = B < ng ? B : ng;
+      const dim3 grid(wpg * Q.ng), blk(64 * ANA_WAVES);
+      const int MTq = (Q.R + 15) / 16;
+      if (MTq == 1) hipLaunchKernelGGL(k_dft_analysis_rr_h2<1>, grid, blk, 0, st, Q);
+      else if (MTq == 2) hipLaunchKernelGGL(k_dft_analysis_rr_h2<2>, grid, blk, 0, st, Q);
+      else hipLaunchKernelGGL(k_dft_analysis_rr_h2<3>, grid, blk, 0, st, Q);
+      RPDE_LAUNCH_CHECK();
+      return RPDE_OK;
+    }
     if (ana_sq_ok(M, N, cus) && py->h2_ana[adjoint] == px->h2_ana[adjoint]) {
       AnaSqP Q;
       Q.x = x; Q.timg = (const char*)py->h2_ana_p[adjoint]; Q.spec_y = spec_y; Q.spec_x = spec_x; Q.amax_y = amax_y; Q.amax_x = amax_x;

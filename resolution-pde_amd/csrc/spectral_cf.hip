@@ -648,6 +648,46 @@ int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, c
   return conv1x1_syn(x, wc, bc, t1, pn->fs_t, out, B, Cin, Cout, M, N, 2 * kp, act_out, st);
 }
 
+// ---- the LAST block and the projection MLP in one entry point (evaluation): out = mlp2(gelu(mlp1(act(SpectralConv2d(x) +
+// Conv2d_1x1(x))))), reference models/fno.py:143-150.  The spectral branch as in rpde_fnoblock2d_eval_fwd; its last
+// transform, the bypass convolution, the activation and both projection layers are ONE pass over x (conv_proj_h2.hip):
+// the block's output is never written.
+int rpde_fnoblock2d_proj_eval_ok(int Cin, int Cout, int M, int N, int m1, int m2, int Cmid, int Cq) {
+  const int kp = (m2 + 3) / 4 * 4;
+  return m2 <= N / 2 + 1 && m1 <= M && conv_syn_proj_ok(Cin, Cout, M, N, 2 * kp, Cmid, Cq) ? 1 : 0;
+}
+
+int rpde_fnoblock2d_proj_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc,
+                                  const float* pw1, const float* pb1, const float* pw2, const float* pb2, float* out, int B,
+                                  int Cin, int Cout, int M, int N, int m1, int m2, int act_out, int Cmid, int Cq, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  RPDE_CHECK_ARG(x && w1 && w2 && wc && pw1 && pw2 && out && B > 0, "fnoblock2d_proj_eval_fwd: bad arguments");
+  RPDE_CHECK_ARG(rpde_fnoblock2d_proj_eval_ok(Cin, Cout, M, N, m1, m2, Cmid, Cq), "fnoblock2d_proj_eval_fwd: shape not covered");
+  RPDE_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "fnoblock2d_proj_eval_fwd: x must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const rpde_plan *pn, *pm;
+  RPDE_TRY(get_plan(&pn, N, m2, RPDE_NORM_BACKWARD, 1, PLAN_REAL, st));
+  RPDE_TRY(get_plan(&pm, M, m1, RPDE_NORM_BACKWARD, 0, PLAN_CPLX, st));
+  const int kp = pn->kp, R = 2 * m1;
+  Arena ar(ws, ws_bytes);
+  float* s1 = ar.take((size_t)B * Cin * M * 2 * kp);
+  float* t1 = ar.take((size_t)B * Cout * M * 2 * kp);
+  float* o2 = ar.take((size_t)B * Cout * 2 * R * kp);
+  float* s2 = ar.take((size_t)B * Cin * 2 * R * kp);
+  if (!ar.ok()) { set_error("fnoblock2d_proj_eval_fwd: workspace too small"); return RPDE_ERR_WORKSPACE; }
+  RPDE_TRY(cf_analysis(pn, x, s1, (long)B * Cin * M, N, 0, st));
+  MixGeom g{B, Cin, Cout, R, m1, m2, kp};
+  if (col_stage_ok(M, m1, kp, s1, t1)) {
+    RPDE_TRY(col_stage(pm, s1, s2, w1, w2, t1, g, M, st));
+  } else {
+    RPDE_TRY(cf_rowdft(pm->fa, 2L * M, false, 2 * R, 2 * M, s1, s2, B * Cin, kp, st));
+    if (kp != m2) RPDE_HIP(hipMemsetAsync(o2, 0, sizeof(float) * (size_t)B * Cout * 2 * R * kp, st));
+    RPDE_TRY(launch_mix(0, s2, nullptr, w1, w2, o2, nullptr, g, st));
+    RPDE_TRY(cf_rowdft(pm->fs, 2L * R, false, 2 * M, 2 * R, o2, t1, B * Cout, kp, st));
+  }
+  return conv_syn_proj(x, wc, bc, t1, pn->fs_t, pw1, pb1, pw2, pb2, out, B, Cout, M, N, 2 * kp, Cmid, Cq, act_out, st);
+}
+
 // ---- evaluation-mode FNO2d: lifting + first block without the lifted field (reference models/fno.py:121-147:
 // cat(x, gridx, gridy) -> lifting -> fno_blocks[0]); u [B,1,M,N], gx [M], gy [N], wl [C,3], bl [C] ----
 size_t rpde_fno2d_lift_block_eval_ws_bytes(int B, int C, int Cout, int M, int N, int m1, int m2) {

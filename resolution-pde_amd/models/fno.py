@@ -97,8 +97,17 @@ class FNO2d(_FNO):
                                           blk.spectral_conv.weights2, blk.bypass_conv.weight, blk.bypass_conv.bias,
                                           act_name(blk.activation))
             if h is not None:
-                for b in self.fno_blocks[1:]:
+                for b in self.fno_blocks[1:-1]:
                     h = b.activated(h)
+                if len(self.fno_blocks) > 1:
+                    # the last block and the projection in one pass over its input (the block's output is never written)
+                    last, pr = self.fno_blocks[-1], self.projection
+                    out = ops.fnoblock2d_proj_eval(h, last.spectral_conv.weights1, last.spectral_conv.weights2,
+                                                   last.bypass_conv.weight, last.bypass_conv.bias, act_name(last.activation),
+                                                   pr.mlp1.weight, pr.mlp1.bias, pr.mlp2.weight, pr.mlp2.bias)
+                    if out is not None:
+                        return out
+                    h = last.activated(h)
                 return self.projection(h, "identity")
         gx = gy = None
         if self.grid is not None:

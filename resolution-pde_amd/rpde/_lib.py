@@ -114,6 +114,8 @@ _SIGNATURES = {
     "rpde_fnoblock2d_eval_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "rpde_fnoblock2d_eval_ok": (_I, [_I, _I, _I, _I, _I]),
     "rpde_fnoblock2d_eval_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
+    "rpde_fnoblock2d_proj_eval_ok": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "rpde_fnoblock2d_proj_eval_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "rpde_conv_mlp_ok": (_I, [_I, _I, _I, _L]),
     "rpde_conv_mlp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P]),
     "rpde_conv1x1_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P, _Z, _P]),

@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False, defin
             FLAGS.append("-DRPDE_STAMPS")
     elif define:
         OBJDIR, LIB = os.path.join(REPO, "build", "rpde_" + define), os.path.join(LIBDIR, f"librpde_hip_{define}.so")
-        FLAGS.append("-D" + define)
+        FLAGS.extend("-D" + d for d in define.split(","))
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hdr = _newest_header()

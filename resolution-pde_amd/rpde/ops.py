@@ -563,6 +563,34 @@ def fnoblock2d_eval(x, w1, w2, wc, bc, act_out: str):
     return out
 
 
+def fnoblock2d_proj_eval(x, w1, w2, wc, bc, act_out: str, pw1, pb1, pw2, pb2):
+    """evaluation only (no autograd): the LAST FNO block and the projection MLP in one library call --
+    mlp2(gelu(mlp1(act_out(SpectralConv2d(x; w1, w2) + conv1x1(x; wc, bc))))) -- without the block's output ever being
+    written (rpde_fnoblock2d_proj_eval_fwd); None when the shape is not covered"""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or w1.shape[3] > x.shape[-1] // 2 + 1 or w1.shape[2] > x.shape[-2]:
+        return None
+    B, Ci, M, N = x.shape
+    Co, m1, m2 = w1.shape[1], w1.shape[2], w1.shape[3]
+    Cm, Cq = pw1.shape[0], pw2.shape[0]
+    if pw1[0].numel() != Co or pw2[0].numel() != Cm or not lib.rpde_fnoblock2d_proj_eval_ok(Ci, Co, M, N, m1, m2, Cm, Cq):
+        return None
+    x = _f32c(x)
+    wcf = _f32c(wc.detach()).reshape(Co, Ci)
+    bcf = _f32c(bc.detach()) if bc is not None else None
+    p1, p2 = _f32c(pw1.detach()).reshape(Cm, Co), _f32c(pw2.detach()).reshape(Cq, Cm)
+    q1 = _f32c(pb1.detach()) if pb1 is not None else None
+    q2 = _f32c(pb2.detach()) if pb2 is not None else None
+    out = torch.empty(B, Cq, M, N, dtype=torch.float32, device=x.device)
+    nws = lib.rpde_fnoblock2d_eval_ws_bytes(B, Ci, Co, M, N, m1, m2)
+    ws = workspace(nws, x.device)
+    check(lib.rpde_fnoblock2d_proj_eval_fwd(ptr(x), ptr(_as_float_storage(w1.detach())), ptr(_as_float_storage(w2.detach())),
+                                            ptr(wcf), ptr(bcf), ptr(p1), ptr(q1), ptr(p2), ptr(q2), ptr(out), B, Ci, Co, M, N, m1,
+                                            m2, ACT[act_out], Cm, Cq, ws.data_ptr(), nws, stream_ptr()),
+          "fnoblock2d_proj_eval_fwd")
+    return out
+
+
 def fno2d_lift_block_eval(u, gx, gy, wl, bl, w1, w2, wc, bc, act_out: str):
     """evaluation only (no autograd): act_out(SpectralConv2d(x0) + conv1x1(x0)) with x0 = lifting(cat(u, gx, gy)) formed on
     the fly (rpde_fno2d_lift_block_eval_fwd: the lifted field is never written); u [B,1,M,N], gx [M], gy [N] device

@@ -379,6 +379,44 @@ def test_fused_projection_mlp_matches_float64(gpu_device, shape, act_in):
             os.environ["RPDE_CONV_MLP"] = old
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 12, 12, 128, 1), (1, 20, 33, 128, 6, 8, 64, 2), (1, 32, 8, 512, 12, 12, 128, 1),
+                                   (3, 32, 40, 48, 5, 9, 100, 3), (2, 17, 5, 16, 2, 3, 24, 4)])
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_last_block_and_projection_in_one_pass(gpu_device, shape, act):
+    """rpde_fnoblock2d_proj_eval_fwd (conv_proj_h2.hip): mlp2(gelu(mlp1(act(SpectralConv2d(x) + bypass(x))))) with the block's
+    output never written, against the two-launch sequence it replaces and against float64 (reference models/fno.py:143-150)"""
+    from rpde import ops
+    B, Co, M, N, m1, m2, Cm, Cq = shape
+    Ci = 32
+    torch.manual_seed(M + N + Cm)
+    x = torch.randn(B, Ci, M, N, device=gpu_device)
+    w1 = (torch.rand(Ci, Co, m1, m2, dtype=torch.cfloat) / (Ci * Co)).to(gpu_device)
+    w2 = (torch.rand(Ci, Co, m1, m2, dtype=torch.cfloat) / (Ci * Co)).to(gpu_device)
+    wc = torch.randn(Co, Ci, 1, 1, device=gpu_device) * 0.2
+    bc = torch.randn(Co, device=gpu_device) * 0.1
+    p1 = torch.randn(Cm, Co, 1, 1, device=gpu_device) * 0.3
+    q1 = torch.randn(Cm, device=gpu_device) * 0.1
+    p2 = torch.randn(Cq, Cm, 1, 1, device=gpu_device) * 0.2
+    q2 = torch.randn(Cq, device=gpu_device) * 0.1
+    with torch.no_grad():
+        got = ops.fnoblock2d_proj_eval(x, w1, w2, wc, bc, act, p1, q1, p2, q2)
+        assert got is not None
+        spec = ops.spectral2d(x, w1, w2)
+        h = ops.conv1x1_act_eval(x, wc, bc, spec.clone(), act)
+        two = ops.conv1x1(ops.conv1x1(h, p1, q1, "identity"), p2, q2, "gelu")
+        xf = torch.fft.rfft2(x.double().cpu())
+        o = torch.zeros(B, Co, M, N // 2 + 1, dtype=torch.complex128)
+        o[:, :, :m1, :m2] = torch.einsum("bixy,ioxy->boxy", xf[:, :, :m1, :m2], w1.cpu().to(torch.complex128))
+        o[:, :, -m1:, :m2] = torch.einsum("bixy,ioxy->boxy", xf[:, :, -m1:, :m2], w2.cpu().to(torch.complex128))
+        pre = torch.fft.irfft2(o, s=(M, N)) + torch.nn.functional.conv2d(x.double().cpu(), wc.double().cpu(), bc.double().cpu())
+        hr = torch.nn.functional.gelu(pre) if act == "gelu" else torch.relu(pre)
+        ref = torch.nn.functional.conv2d(torch.nn.functional.gelu(torch.nn.functional.conv2d(hr, p1.double().cpu(), q1.double().cpu())),
+                                         p2.double().cpu(), q2.double().cpu())
+    assert got.shape == (B, Cq, M, N)
+    assert float((got.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+    assert float((got - two).norm() / two.norm()) < 2e-6
+
+
 def test_fused_evaluation_fnoblock2d_narrow_grid_takes_the_two_step_path(gpu_device):
     """N = 32, width 32, 12 modes (the lowest grid of the default all-resolution sweep): the one-pass tail would keep
     32 rows x 24 spectrum entries x 32 channels = 96 KB of LDS beside its weights -- more than a launch gets.  The

@@ -109,7 +109,8 @@ def _kernel_bodies(tmp_path, source, names):
 @pytest.mark.skipif(_hipcc() is None, reason="hipcc not available")
 def test_no_use_of_asm_loaded_registers_before_the_counted_wait(tmp_path):
     for name, body in _kernel_bodies(tmp_path, "fused_spectral", ("20k_dft_analysis_sq_h2ILi1E", "20k_dft_analysis_sq_h2ILi2E",
-                                                                  "20k_dft_analysis_sq_h2ILi3E")):
+                                                                  "20k_dft_analysis_sq_h2ILi3E", "20k_dft_analysis_rr_h2ILi1E",
+                                                                  "20k_dft_analysis_rr_h2ILi2E", "20k_dft_analysis_rr_h2ILi3E")):
         bad, nloads, nlanded = _pending_violations(body)
         assert nloads >= 32, (name, nloads)              # 8 per axis, prologue + loop
         assert nlanded >= 2, (name, nlanded)
