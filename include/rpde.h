@@ -281,7 +281,7 @@ int rpde_fnoblock2d_eval_fwd(const float* x, const float* w1, const float* w2, c
 /* the LAST block of an FNO2d and its projection MLP in evaluation, one entry point (reference models/fno.py:143-150:
  * fno_blocks[-1] -> projection = mlp2(gelu(mlp1(.)))): out [B,Cq,M,N] = pw2 . gelu(pw1 . act_out(SpectralConv2d(x) +
  * Conv2d_1x1(x)) + pb1) + pb2 with pw1 [Cmid,Cout], pw2 [Cq,Cmid].  The block's output never reaches HBM.  Workspace:
- * rpde_fnoblock2d_eval_ws_bytes.  _ok: Cin = 32, Cout <= 32, Cmid <= 128, Cq <= 4, N % 16 == 0, N <= 1024, m2 <= 16. */
+ * rpde_fnoblock2d_eval_ws_bytes.  _ok: Cin = 32, Cout <= 32, Cmid <= 128, Cq <= 4, N % 64 == 0, N <= 1024, m2 <= 16. */
 int rpde_fnoblock2d_proj_eval_ok(int Cin, int Cout, int M, int N, int m1, int m2, int Cmid, int Cq);
 int rpde_fnoblock2d_proj_eval_fwd(const float* x, const float* w1, const float* w2, const float* wc, const float* bc,
                                   const float* pw1, const float* pb1, const float* pw2, const float* pb2, float* out, int B,
