@@ -689,15 +689,18 @@ def main():
                     "DFTs + mode mix on the small spectra, then ONE pass for inverse DFT + bypass conv + GELU; fused projection MLP)",
                     16 * 337.6e6, c5_model16_ms, samples_per_s=round(16 / c5_model16_ms * 1e3, 1)),
             ],
-            "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_mix_prep + k_dft_analysis_sq_h2 (both axes, the field read "
-                                     "from HBM once) + k_mix_h2 (mode mix of both axes, writes the synthesis operands) + "
-                                     "k_dft_synthesis3_h2 (field written once)",
+            "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_mix_prep + k_dft_analysis_rr_h2 (both axes, the field read "
+                                     "from HBM once, no cross-wave sums) + k_mix_h2 (mode mix of both axes, writes the synthesis "
+                                     "operands) + k_dft_synthesis4_h2 (field written once, whole 128-byte lines)",
                                      s_bytes, s_ms, traffic=spec_traffic,
                                      traffic_over_algorithmic=(round(spec_traffic / s_bytes, 3) if spec_traffic else None),
                                      backward_ms=round(s_bwd_ms, 4), backward_frac=round(2 * s_bytes / (s_bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                      note="HBM traffic of the four launches (PMC, profiles/): field 1x in + 1x out, spectra "
                                      "written and read once as fp32 and once as operand fragments; the second read of the field "
-                                     "(the other axis) is served by the L2 of the XCD that read it first"),
+                                     "(the other axis) is served by the L2 of the XCD that read it first.  What bounds the two big "
+                                     "kernels is the rate at which a CU's vector-memory pipeline moves bytes (~10 B/cycle from HBM, "
+                                     "~23 from L2): every field byte is LOADED twice by the analysis, 2.25 fragment bytes per byte "
+                                     "stored by the synthesis -- DESIGN.md section 4.1"),
         }
         if step_traffic:
             # whole training step against the HBM roof: PMC-measured bytes of one step / this run's step time

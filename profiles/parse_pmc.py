@@ -41,7 +41,8 @@ def main(kf, kw, sf, sw, B, steps, out, source):
         blob["dominant_kernel"] = {f"B{B}": res[dom[0]]["hbm_bytes_per_launch"], "kernel": dom[0]}
     blob["per_kernel"] = {f"B{B}": res}
     # FSpectralConv2d.forward_fourier = weight preparation + analysis + mode mix + synthesis (no skip tensor)
-    parts = [k for k in res if k.startswith(("k_mix_prep", "k_dft_analysis_sq_h2", "k_dft_analysis_h2", "k_mix_h2")) or
+    parts = [k for k in res if k.startswith(("k_mix_prep", "k_dft_analysis_rr_h2", "k_dft_analysis_sq_h2", "k_dft_analysis_h2",
+                                             "k_mix_h2", "k_dft_synthesis4_h2")) or
              (k.startswith("k_dft_synthesis3_h2") and "false" in k)]
     if parts:
         blob["spectral_forward"] = {f"B{B}": sum(res[k]["hbm_bytes_per_launch"] for k in parts), "kernels": sorted(parts)}
