@@ -823,7 +823,14 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A0) 
       h2_scale(dzb, 0, sdz, sdzi);
       uint2 hi, lo;
       h2_split4(dz[0] * sdz, dz[1] * sdz, dz[2] * sdz, dz[3] * sdz, hi, lo);
-      const unsigned dst = lds0 + FB_DZBUF + (((ptl >> 4) * 2 + (li >> 3)) * 2) * 1024 + ((li & 3) * 16 + (ptl & 15)) * 16 + ((li >> 2) & 1) * 8;
+      // (the 16-byte unit of fragment lane (c, p) = (li & 3, ptl & 15) sits at unit 16 c + (p ^ c ^ 4 ks) of its 1 KB piece:
+      //  written plainly at 16 c + p, the sixteen lanes of a row -- same p, four c, two ks, 256 / 2048 bytes apart -- hit
+      //  two banks (8-way conflicts: 29.4 M conflict cycles per launch in round 3's counters); permuted inside each
+      //  256-byte row they cover all 32.  The reader un-permutes its address; its own banking only sees a row's units
+      //  in another order.)
+      const int ksz = li >> 3, cz = li & 3;
+      const unsigned dst = lds0 + FB_DZBUF + (((ptl >> 4) * 2 + ksz) * 2) * 1024 + (cz * 16 + ((ptl & 15) ^ cz ^ (4 * ksz))) * 16 +
+                           ((li >> 2) & 1) * 8;
       fb_lds_write_b64(dst, hi);
       fb_lds_write_b64(dst + 1024, lo);
       if (li == 0) fb_lds_write_b32(lds0 + FB_INFO + ptl * 4, dzb);
@@ -858,9 +865,10 @@ __global__ __launch_bounds__(64 * FF_WAVES, 2) void k_ff3_bwd_h2(const FF3B A0) 
       dq[0] = fb_lds_read_b128(lds0 + FB_D2 + (w * 4 + blk * 2) * 1024 + l * 16);
       dq[1] = fb_lds_read_b128(lds0 + FB_D2 + (w * 4 + blk * 2 + 1) * 1024 + l * 16);
       fb_lds_wait2(dq[0], dq[1]);
-      const char* zb = smem + FB_DZBUF + (blk * 2) * 2048 + l * 16;
-      const f16x8 zh0 = *reinterpret_cast<const f16x8*>(zb), zl0 = *reinterpret_cast<const f16x8*>(zb + 1024);
-      const f16x8 zh1 = *reinterpret_cast<const f16x8*>(zb + 2048), zl1 = *reinterpret_cast<const f16x8*>(zb + 3072);
+      const int zu = (l & 48) | ((l & 15) ^ (l >> 4));             // this lane's unit in the ks = 0 pieces; ks = 1: ^ 4
+      const char* zb = smem + FB_DZBUF + (blk * 2) * 2048;
+      const f16x8 zh0 = *reinterpret_cast<const f16x8*>(zb + zu * 16), zl0 = *reinterpret_cast<const f16x8*>(zb + 1024 + zu * 16);
+      const f16x8 zh1 = *reinterpret_cast<const f16x8*>(zb + 2048 + (zu ^ 4) * 16), zl1 = *reinterpret_cast<const f16x8*>(zb + 3072 + (zu ^ 4) * 16);
       const long pt = p0 + 16 * blk + li;
       float inv_a, s_du2, q0, q1, q2;
       bscales(blk, inv_a, s_du2, q0, q1, q2);

@@ -145,7 +145,13 @@ class ResolutionGroupedDataLoader:
                 if buf is None or buf.shape[0] < len(parts) or buf.shape[1:] != parts[0].shape or buf.dtype != parts[0].dtype:
                     buf = torch.empty((self.batch_size,) + tuple(parts[0].shape), dtype=parts[0].dtype).pin_memory()
                     self._pinned[key] = buf
-                out.append(torch.stack(parts, out=buf[:len(parts)]))
+                # (sample by sample: torch.stack(..., out=) into a preallocated buffer takes ~50 ms for 32 fields of 256^2 once
+                #  torch runs its copy kernel multi-threaded, against ~1 ms this way -- it starved the GPU in front of small-grid
+                #  steps)
+                view = buf[:len(parts)]
+                for i, part in enumerate(parts):
+                    view[i].copy_(part)
+                out.append(view)
             yield tuple(out)
         self.epoch += 1
 
