@@ -255,6 +255,13 @@ int rpde_linear_bwd(const float* x, const float* w, const float* grad_out,
                     float* grad_x, float* grad_w, float* grad_b,
                     int64_t P, int in_f, int out_f, void* ws, size_t ws_bytes, void* stream);
 
+/* Weight normalisation of WNLinear (models/custom_layer.py:70-108: torch.nn.utils.weight_norm on dim 0, parameters
+ * weight_g [out,1], weight_v [out,in]):  w = v * (g / |v|_row), and its adjoint -- one launch each where autograd runs
+ * a dozen ATen kernels per projection.  grad_v or grad_g may be null. */
+int rpde_weight_norm_fwd(const float* v, const float* g, float* w, int out_f, int in_f, void* stream);
+int rpde_weight_norm_bwd(const float* v, const float* g, const float* grad_w, float* grad_v, float* grad_g,
+                         int out_f, int in_f, void* stream);
+
 /* ---- 1x1 convolution, channels-first: nn.Conv1d/Conv2d(k=1) lifting, bypass
  * and projection (models/fno.py:30,93; fno_blocks.py:29,38-39,67,76-77).
  * x [B,Cin,S], w [Cout,Cin], out [B,Cout,S] (S = flattened spatial size).

@@ -47,7 +47,7 @@ static inline int wgrad_split(long P, int out_f, int in_f) {
 static inline bool worth_presplit(long P, int n, int k) { return P >= 1024 && k % 32 == 0 && n > 32; }
 static int linear_fwd_impl(const float* x, const float* w, const float* b, float* y, long P, int in_f, int out_f,
                            int act_out, float* dy, float drop_p, uint64_t drop_seed, hipStream_t st,
-                           void* wimg = nullptr, const uint64_t* drop_epoch = nullptr) {
+                           void* wimg = nullptr, const uint64_t* drop_epoch = nullptr, bool wimg_ready = false) {
   if (act_out == RPDE_ACT_IDENTITY && !dy && drop_p == 0.f) {
     // lifting / projection shapes: streaming kernels instead of degenerate GEMMs (thin_linear.hip)
     if (in_f <= 4 && thin_linear_ok(in_f, out_f) && al16(y)) return thin_expand(x, w, in_f, 1, b, y, P, in_f, out_f, st);
@@ -57,7 +57,7 @@ static int linear_fwd_impl(const float* x, const float* w, const float* b, float
   d.A = x; d.a_kmajor = 1; d.lda = in_f;
   d.B = w; d.b_kmajor = 1; d.ldb = in_f;
   if (wimg && worth_presplit(P, out_f, in_f)) {
-    RPDE_TRY(split_weights(w, 1, in_f, out_f, in_f, wimg, st));
+    if (!wimg_ready) RPDE_TRY(split_weights(w, 1, in_f, out_f, in_f, wimg, st));
     d.b_split = wimg;
   }
   d.C = y; d.ldc = out_f;
@@ -71,7 +71,8 @@ static int linear_fwd_impl(const float* x, const float* w, const float* b, float
 // gw[out,in] = gy[P,out]^T . act_in(x)[P,in]   (split over P, slabs reduced here);  gb = colsum(gy)
 // act_x: the x operand is act_x(x) (recompute mode of the fused FeedForward: x holds u, the layer's input is gelu(u))
 static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* gb, long P, int in_f, int out_f,
-                             float* ws_slabs, float* ws_colsum, hipStream_t st, int act_x = RPDE_ACT_IDENTITY) {
+                             float* ws_slabs, float* ws_colsum, hipStream_t st, int act_x = RPDE_ACT_IDENTITY,
+                             FoldJobs* defer = nullptr) {
   if (act_x == RPDE_ACT_IDENTITY && (gw || gb)) {
     // one pass over both operands gives the weight gradient and the bias gradient of a lifting / projection layer
     if (in_f <= 4 && thin_linear_ok(in_f, out_f) && al16(gy)) return thin_outer(x, gy, gw, 1, gb, nullptr, P, in_f, out_f, ws_slabs, st);
@@ -88,7 +89,9 @@ static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* 
     if (S > 1) {
       d.C = ws_slabs; d.ldc = in_f; d.ksplit = S; d.sCk = (long)out_f * in_f;
       RPDE_TRY(launch_gemm(d, st));
-      RPDE_TRY(reduce_slabs(ws_slabs, gw, (long)out_f * in_f, S, (long)out_f * in_f, 1.f, 0, st));
+      // (defer: the caller folds every slab set of its backward pass in one launch; ws_slabs is then its own region)
+      if (!(defer && defer->add(ws_slabs, gw, out_f * in_f, S, (long)out_f * in_f)))
+        RPDE_TRY(reduce_slabs(ws_slabs, gw, (long)out_f * in_f, S, (long)out_f * in_f, 1.f, 0, st));
     } else {
       d.C = gw; d.ldc = in_f;
       RPDE_TRY(launch_gemm(d, st));
@@ -111,7 +114,8 @@ static inline bool can_fuse_colsum(const float* gy, const float* w, const float*
 // wimg: optional scratch of split_bytes(in_f, out_f): W (x-major here) is split into k-major bf16 images
 // first, which is what lets this GEMM take the split-bf16 path at all
 static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P, int in_f, int out_f,
-                             const float* dstored, float* colsum_slab, hipStream_t st, void* wimg = nullptr) {
+                             const float* dstored, float* colsum_slab, hipStream_t st, void* wimg = nullptr,
+                             bool wimg_ready = false) {
   if (!dstored && !colsum_slab) {
     if (out_f <= 4 && thin_linear_ok(out_f, in_f) && al16(gx)) return thin_expand(gy, w, 1, in_f, nullptr, gx, P, out_f, in_f, st);
     if (in_f <= 4 && thin_linear_ok(in_f, out_f) && al16(gy)) return thin_contract(gy, w, 1, in_f, nullptr, gx, P, in_f, out_f, st);
@@ -120,7 +124,7 @@ static int linear_dgrad_impl(const float* gy, const float* w, float* gx, long P,
   d.A = gy; d.a_kmajor = 1; d.lda = out_f;
   d.B = w; d.b_kmajor = 0; d.ldb = in_f;
   if (wimg && worth_presplit(P, in_f, out_f)) {
-    RPDE_TRY(split_weights(w, 0, in_f, in_f, out_f, wimg, st));
+    if (!wimg_ready) RPDE_TRY(split_weights(w, 0, in_f, in_f, out_f, wimg, st));
     d.b_split = wimg;
   }
   d.C = gx; d.ldc = in_f;
@@ -150,20 +154,18 @@ using namespace rpde;
 extern "C" {
 
 // ------------------------------ FeedForward --------------------------------
+// backward workspace of the GEMM path: every layer has its own weight-gradient slabs, column-sum slabs and weight
+// images, so that the folds and the splits of the whole pass are one launch each (FoldJobs, SplitJobs)
 size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
   const int hid = n_layers > 1 ? dim * factor : dim;
-  size_t slabs = 0;
+  size_t n = 2 * arena_bytes((size_t)P * hid);
   for (int l = 0; l < n_layers; ++l) {
     const int i = l == 0 ? dim : dim * factor, o = l == n_layers - 1 ? dim : dim * factor;
-    const size_t s = wgrad_ws_floats(P, i, o);
-    if (s > slabs) slabs = s;
+    n += arena_bytes(wgrad_ws_floats(P, i, o));
+    n += arena_bytes((size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid);
+    n += arena_bytes(ff_wimg_floats(hid));
   }
-  size_t small = colsum_ws_floats(P, hid);
-  const size_t t = ff_tail_bwd_ws_floats(P, dim);
-  if (t > small) small = t;
-  const size_t c = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
-  if (c > small) small = c;
-  size_t n = 2 * arena_bytes((size_t)P * hid) + arena_bytes(slabs) + arena_bytes(small) + arena_bytes(ff_wimg_floats(hid));
+  n += arena_bytes(colsum_ws_floats(P, hid)) + arena_bytes(ff_tail_bwd_ws_floats(P, dim));
   rpde_ff_params q;
   memset(&q, 0, sizeof(q));
   q.dim = dim; q.factor = factor; q.n_layers = n_layers;
@@ -173,7 +175,7 @@ size_t rpde_feedforward_ws_bytes(int64_t P, int dim, int factor, int n_layers) {
 }
 
 size_t rpde_feedforward_fwd_ws_bytes(int dim, int factor, int n_layers) {
-  const size_t a = arena_bytes(ff_wimg_floats(n_layers > 1 ? dim * factor : dim)), b = arena_bytes(ff3_fused_ws_floats());
+  const size_t a = (size_t)n_layers * arena_bytes(ff_wimg_floats(n_layers > 1 ? dim * factor : dim)), b = arena_bytes(ff3_fused_ws_floats());
   return a > b ? a : b;
 }
 
@@ -220,16 +222,31 @@ int rpde_feedforward_fwd(const rpde_ff_params* p, const float* x, const float* r
   const int L = p->n_layers;
   // optional scratch (rpde_feedforward_fwd_ws_bytes): weights are pre-split once per call; without it the
   // GEMMs split them per workgroup (slower, same bits)
+  // (one image per layer, all of them split by ONE launch: with a single image the layers split theirs one by one)
   Arena ar(ws, ws_bytes);
-  void* wimg = ws ? ar.take(ff_wimg_floats(L > 1 ? p->dim * p->factor : p->dim)) : nullptr;
-  if (!ar.ok()) wimg = nullptr;
+  const size_t img_floats = ff_wimg_floats(L > 1 ? p->dim * p->factor : p->dim);
+  float* wimg[SplitJobs::MAX] = {nullptr, nullptr, nullptr, nullptr};
+  bool all_imgs = ws != nullptr && L <= SplitJobs::MAX;
+  for (int l = 0; l < (all_imgs ? L : 1) && ws; ++l) {
+    float* t = ar.take(img_floats);
+    if (!t) { all_imgs = false; break; }
+    wimg[l] = t;
+  }
+  if (all_imgs) {
+    SplitJobs sj;
+    for (int l = 0; l < L; ++l) {
+      RPDE_CHECK_ARG(p->weights[l], "feedforward_fwd: null layer %d weight", l);
+      if (worth_presplit(P, ff_out(p, l), ff_in(p, l))) sj.add(p->weights[l], 1, ff_in(p, l), ff_out(p, l), ff_in(p, l), wimg[l]);
+    }
+    RPDE_TRY(split_weights_multi(sj, st));
+  }
   for (int l = 0; l < L; ++l) {
     const bool last = l == L - 1;
     RPDE_CHECK_ARG(p->weights[l] && (last || hs[l]), "feedforward_fwd: null layer %d buffers", l);
     const float* in = l == 0 ? x : hs[l - 1];
     RPDE_TRY(linear_fwd_impl(in, p->weights[l], p->biases ? p->biases[l] : nullptr, last ? z_last : hs[l], P, ff_in(p, l),
                              ff_out(p, l), last ? RPDE_ACT_IDENTITY : RPDE_ACT_GELU, (last || !ds) ? nullptr : ds[l],
-                             p->dropout_p, layer_seed(p->seed, l), st, wimg, p->seed_epoch));
+                             p->dropout_p, layer_seed(p->seed, l), st, all_imgs ? wimg[l] : wimg[0], p->seed_epoch, all_imgs));
   }
   return ff_tail_fwd(z_last, residual, out, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
                      make_drop(p->dropout_p, layer_seed(p->seed, L - 1), p->seed_epoch), p->post_act, st);
@@ -245,18 +262,21 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   hipStream_t st = as_stream(stream);
   const int L = p->n_layers;
   const int hid = L > 1 ? p->dim * p->factor : p->dim;
+  RPDE_CHECK_ARG(L <= 8, "feedforward_bwd: %d layers", L);
   Arena ar(ws, ws_bytes);
   float* buf0 = ar.take((size_t)P * hid);
   float* buf1 = ar.take((size_t)P * hid);
-  size_t slabs_n = 0;
-  for (int l = 0; l < L; ++l) { const size_t s = wgrad_ws_floats(P, ff_in(p, l), ff_out(p, l)); if (s > slabs_n) slabs_n = s; }
-  float* slabs = ar.take(slabs_n);
-  size_t small_n = colsum_ws_floats(P, hid);
-  if (ff_tail_bwd_ws_floats(P, p->dim) > small_n) small_n = ff_tail_bwd_ws_floats(P, p->dim);
-  if ((size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid > small_n) small_n = (size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid;
-  float* small = ar.take(small_n);
-  void* wt = ar.take(ff_wimg_floats(hid));
+  // per layer: weight-gradient slabs, column-sum slabs, weight image (rpde_feedforward_ws_bytes) -- the regions of layer
+  // 0 are followed by the others', so the fused path below may use them as one region of the largest layer's size
+  float* slabs_l[8]; float* csum_l[8]; float* wt_l[8];
+  for (int l = 0; l < L; ++l) slabs_l[l] = ar.take(wgrad_ws_floats(P, ff_in(p, l), ff_out(p, l)));
+  for (int l = 0; l < L; ++l) csum_l[l] = ar.take((size_t)(colsum_tiles(P) + REDUCE_CHUNKS) * hid);
+  for (int l = 0; l < L; ++l) wt_l[l] = ar.take(ff_wimg_floats(hid));
+  float* small = ar.take(colsum_ws_floats(P, hid));
+  float* tailws = ar.take(ff_tail_bwd_ws_floats(P, p->dim));
   if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
+  float* slabs = slabs_l[0];
+  void* wt = wt_l[0];
 
   if (ff3_fused_ok(p, P) && hs && hs[0] && hs[1]) {
     // ds given: they hold d = gelu'(u) * dropscale and hs hold h.  ds absent: recompute mode, hs hold u = dropout(z)
@@ -295,33 +315,46 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   }
 
   // tail: d(out) -> dz_{L-1}, d(gamma), d(beta) and, fused, the last layer's bias gradient
+  // every fold of the pass (LayerNorm / bias sums of the tail, weight-gradient slabs, column sums) is collected and done
+  // by one launch at the end; the transposed weight images of all layers are split by one launch at the start
+  FoldJobs folds;
   float* dz = buf0;
   float* other = buf1;
   int bias_done = 0;      // grad_biases[l] already produced by the kernel that produced dz_l
   RPDE_TRY(ff_tail_bwd(z_last, grad_out, dz, P, p->dim, p->layer_norm, p->ln_eps, p->ln_gamma, p->ln_beta,
                        make_drop(p->dropout_p, layer_seed(p->seed, L - 1), p->seed_epoch), p->post_act, grad_gamma, grad_beta,
-                       grad_biases ? grad_biases[L - 1] : nullptr, &bias_done, small, st));
+                       grad_biases ? grad_biases[L - 1] : nullptr, &bias_done, tailws, st, &folds));
+  const bool all_imgs = L <= SplitJobs::MAX;
+  if (all_imgs) {
+    SplitJobs sj;
+    for (int l = grad_x ? 0 : 1; l < L; ++l)
+      if (worth_presplit(P, ff_in(p, l), ff_out(p, l))) sj.add(p->weights[l], 0, ff_in(p, l), ff_in(p, l), ff_out(p, l), wt_l[l]);
+    RPDE_TRY(split_weights_multi(sj, st));
+  }
   for (int l = L - 1; l >= 0; --l) {
     const int in_f = ff_in(p, l), out_f = ff_out(p, l);
     const float* in = l == 0 ? x : hs[l - 1];
     float* gb = (grad_biases && !bias_done) ? grad_biases[l] : nullptr;
-    RPDE_TRY(linear_wgrad_impl(in, dz, grad_weights ? grad_weights[l] : nullptr, gb, P, in_f, out_f, slabs, small, st));
+    RPDE_TRY(linear_wgrad_impl(in, dz, grad_weights ? grad_weights[l] : nullptr, gb, P, in_f, out_f, slabs_l[l], small, st,
+                               RPDE_ACT_IDENTITY, &folds));
     bias_done = 0;
+    void* img = all_imgs ? wt_l[l] : wt;
     if (l > 0) {
       RPDE_CHECK_ARG(ds[l - 1], "feedforward_bwd: derivative of layer %d was not saved", l - 1);
       const bool fuse = grad_biases && can_fuse_colsum(dz, p->weights[l], other, ds[l - 1], P, in_f, out_f);
-      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, ds[l - 1], fuse ? small : nullptr, st, wt));
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[l], other, P, in_f, out_f, ds[l - 1], fuse ? csum_l[l] : nullptr, st, img, all_imgs));
       if (fuse) {
-        RPDE_TRY(reduce_slabs_2pass(small, grad_biases[l - 1], in_f, (int)colsum_tiles(P), in_f,
-                                    small + colsum_tiles(P) * in_f, st));
+        const int S = (int)colsum_tiles(P);
+        if (!(S <= 4 * REDUCE_CHUNKS && folds.add(csum_l[l], grad_biases[l - 1], in_f, S, in_f)))
+          RPDE_TRY(reduce_slabs_2pass(csum_l[l], grad_biases[l - 1], in_f, S, in_f, csum_l[l] + colsum_tiles(P) * in_f, st));
         bias_done = 1;
       }
       float* t = dz; dz = other; other = t;
     } else if (grad_x) {
-      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, nullptr, nullptr, st, wt));
+      RPDE_TRY(linear_dgrad_impl(dz, p->weights[0], grad_x, P, in_f, out_f, nullptr, nullptr, st, img, all_imgs));
     }
   }
-  return RPDE_OK;
+  return fold_jobs(folds, st);
 }
 
 // ------------------------------ nn.Linear ----------------------------------

@@ -16,6 +16,7 @@
 #include "plan.h"
 #include "pointwise.h"
 #include "fused_spectral.h"
+#include "mix1d.h"
 
 #include <stdlib.h>
 
@@ -129,7 +130,13 @@ static int axis_fwd(const Axis& ax, const float* x, const float* w, int K, float
                     int accumulate, Arena& ar, hipStream_t st) {
   RPDE_TRY(dft_analysis(ax, x, spec_in, C, false, st));
   const float* syn_in = spec_in;
-  if (mode == RPDE_MODE_FULL) {
+  if (mode == RPDE_MODE_FULL && mix1d_ok(ax.rows, C)) {
+    // few rows (the 1-D layer): the mix reads the weights where they lie (mix1d.hip)
+    float* mixed = ar.take(spec_floats(ax, C));
+    if (!ar.ok()) { set_error("fspectral: workspace too small"); return RPDE_ERR_WORKSPACE; }
+    RPDE_TRY(mix1d(spec_in, w, mixed, ax.rows, C, K, ax.keff, ax.kp, false, st));
+    syn_in = mixed;
+  } else if (mode == RPDE_MODE_FULL) {
     float* wblk = ar.take((size_t)ax.keff * 4 * C * C);
     float* mixed = ar.take(spec_floats(ax, C));
     if (!ar.ok()) { set_error("fspectral: workspace too small"); return RPDE_ERR_WORKSPACE; }
@@ -148,7 +155,15 @@ static int axis_bwd(const Axis& ax, const float* g, const float* spec_in, const 
   if (!ar.ok()) { set_error("fspectral: workspace too small"); return RPDE_ERR_WORKSPACE; }
   RPDE_TRY(dft_analysis(ax, g, gspec, C, true, st));
   const float* dspec = gspec;
-  if (mode == RPDE_MODE_FULL) {
+  if (mode == RPDE_MODE_FULL && mix1d_ok(ax.rows, C)) {
+    float* dsp = ar.take(spec_floats(ax, C));
+    if (!ar.ok()) { set_error("fspectral: workspace too small"); return RPDE_ERR_WORKSPACE; }
+    if (gw) RPDE_TRY(mix1d_wgrad(spec_in, gspec, gw, ax.rows, C, K, ax.keff, ax.kp, st));
+    if (gx) {
+      RPDE_TRY(mix1d(gspec, w, dsp, ax.rows, C, K, ax.keff, ax.kp, true, st));
+      dspec = dsp;
+    }
+  } else if (mode == RPDE_MODE_FULL) {
     float* wblk = ar.take((size_t)ax.keff * 4 * C * C);
     float* dsp = ar.take(spec_floats(ax, C));
     const int S = split_for(ax.rows, wgrad_tiles(C) * ax.keff);

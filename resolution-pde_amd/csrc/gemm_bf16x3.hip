@@ -501,9 +501,10 @@ static void launch_x3_layout(const GemmK& g, bool ak, bool bk, dim3 grid, hipStr
 
 // fp32 weights [N,K] (k-major, ld) or [K,N] (x-major) -> [K/32][3][Npad][32] bf16 images, 16-byte chunks of
 // each 64-byte row XOR-swizzled with (row>>2)&3 (= the LDS image of a stage), pad rows zero
-__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, int kmajor, long ld, int N, int K,
-                                                       int npad, char* __restrict__ out) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+int split_npad(int N) { return ((N + 127) / 128) * 128; }
+
+__device__ __forceinline__ void split_weights_thread(long t, const float* __restrict__ w, int kmajor, long ld, int N, int K,
+                                                     int npad, char* __restrict__ out) {
   const int kchunks = ((K + XBK - 1) / XBK) * (XBK / 8);
   if (t >= (long)npad * kchunks) return;
   const int n = (int)(t % npad), kc = (int)(t / npad);     // consecutive threads: consecutive rows
@@ -522,7 +523,25 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
   *reinterpret_cast<uint4*>(p + 2L * npad * 64) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-int split_npad(int N) { return ((N + 127) / 128) * 128; }
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, int kmajor, long ld, int N, int K,
+                                                       int npad, char* __restrict__ out) {
+  split_weights_thread((long)blockIdx.x * 256 + threadIdx.x, w, kmajor, ld, N, K, npad, out);
+}
+
+// the images of several weights in one launch (all layers of a FeedForward: the small configurations are launch-bound)
+__global__ __launch_bounds__(256) void k_split_weights_multi(const SplitJobs J) {
+  int jn = 0;
+#pragma unroll
+  for (int q = 1; q < SplitJobs::MAX; ++q)
+    if (q < J.n && (int)blockIdx.x >= J.j[q].blk0) jn = q;
+  SplitJobs::Job jb = J.j[0];
+#pragma unroll
+  for (int q = 1; q < SplitJobs::MAX; ++q)
+    if (q == jn) jb = J.j[q];
+  split_weights_thread((long)((int)blockIdx.x - jb.blk0) * 256 + threadIdx.x, jb.w, jb.kmajor, jb.ld, jb.N, jb.K, ((jb.N + 127) / 128) * 128,
+                       jb.out);
+}
+
 size_t split_bytes(int N, int K) { return (size_t)((K + XBK - 1) / XBK) * 3 * split_npad(N) * 64; }
 
 int split_weights(const float* w, int kmajor, long ld, int N, int K, void* out, hipStream_t st) {
@@ -533,6 +552,21 @@ int split_weights(const float* w, int kmajor, long ld, int N, int K, void* out, 
   hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, w, kmajor, ld, N, K, npad,
                      static_cast<char*>(out));
   RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+int split_weights_multi(SplitJobs& J, hipStream_t st) {
+  if (J.n == 0) return RPDE_OK;
+  int blocks = 0;
+  for (int q = 0; q < J.n; ++q) {
+    RPDE_CHECK_ARG(J.j[q].w && J.j[q].out && (reinterpret_cast<uintptr_t>(J.j[q].out) & 15) == 0, "split_weights_multi: bad job %d", q);
+    const long threads = (long)split_npad(J.j[q].N) * ((J.j[q].K + XBK - 1) / XBK) * (XBK / 8);
+    J.j[q].blk0 = blocks;
+    blocks += (int)((threads + 255) / 256);
+  }
+  hipLaunchKernelGGL(k_split_weights_multi, dim3((unsigned)blocks), dim3(256), 0, st, J);
+  RPDE_LAUNCH_CHECK();
+  J.n = 0;
   return RPDE_OK;
 }
 

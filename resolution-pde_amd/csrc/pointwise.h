@@ -8,6 +8,21 @@ int reduce_slabs(const float* slabs, float* out, long n, int S, long stride, flo
 // out_k[j] = sum_s slabs[s*stride + off_k + j] for up to eight segments of one slab row, one launch; null dst: skipped
 struct ReduceSegs { int n, nseg; int off[8]; int len[8]; float* dst[8]; };
 int reduce_slabs_seg(const float* slabs, int S, long stride, const ReduceSegs& sg, hipStream_t st);
+// folds collected over several kernels and done by ONE launch (the small configurations are launch-bound: a FeedForward
+// backward on the GEMM path has eight of them).  Each job is out[i] = sum_s src[s*stride + i], i < len, summed exactly as
+// reduce_slabs does it (same bits).
+struct FoldJobs {
+  static constexpr int MAX = 12;
+  int n = 0;
+  struct Job { const float* src; float* dst; long stride; int len, S, blk0; } j[MAX];
+  bool add(const float* src, float* dst, int len, int S, long stride) {
+    if (n >= MAX) return false;
+    j[n].src = src; j[n].dst = dst; j[n].len = len; j[n].S = S; j[n].stride = stride; j[n].blk0 = 0;
+    ++n;
+    return true;
+  }
+};
+int fold_jobs(FoldJobs& jobs, hipStream_t st);
 constexpr int REDUCE_CHUNKS = 64;
 // tmp: REDUCE_CHUNKS * n floats of scratch
 int reduce_slabs_2pass(const float* slabs, float* out, long n, int S, long stride, float* tmp, hipStream_t st);
@@ -20,7 +35,7 @@ int ff_tail_fwd(const float* z, const float* res, float* out, long P, int C, int
 size_t ff_tail_bwd_ws_floats(long P, int C);
 int ff_tail_bwd(const float* z, const float* g, float* dz, long P, int C, int layer_norm, float eps, const float* gamma,
                 const float* beta, DropCfg drop, int post_act, float* grad_gamma, float* grad_beta, float* grad_bias,
-                int* bias_done, float* ws, hipStream_t st);
+                int* bias_done, float* ws, hipStream_t st, FoldJobs* defer = nullptr);
 
 int pack_mix_weights(const float* w, float* blk, int Ci, int Co, int K, int keff, hipStream_t st);
 int unpack_mix_grad(const float* slabs, float* gw, int Ci, int Co, int K, int keff, int S, long sstride, hipStream_t st);

@@ -11,13 +11,9 @@ namespace rpde {
 // out[i] (+)= scale * sum_s slabs[s*stride + i]
 // ---------------------------------------------------------------------------
 // 64 consecutive outputs per block; the 4 waves split the slabs, LDS combines them
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long n,
-                                                      int S, long stride, float scale, int accumulate) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + tx;
-  float acc = 0.f;
-  if (i < n) {
+__device__ __forceinline__ float slab_partial(const float* __restrict__ slabs, long i, int S, long stride, int ty) {
+  float acc;
+  {
     // with few outputs and many slabs this loop is pure load latency (2 blocks, 256 slabs: 13 us with eight loads in
     // flight per lane): 32 in flight while there are that many, then 8, then the rest -- the summation order is fixed by
     // S alone, so results stay reproducible
@@ -37,6 +33,15 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
     for (; s < S; s += 4) a[0] += slabs[(long)s * stride + i];
     acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long n,
+                                                      int S, long stride, float scale, int accumulate) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + tx;
+  float acc = i < n ? slab_partial(slabs, i, S, stride, ty) : 0.f;
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && i < n) {
@@ -45,6 +50,35 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
     if (accumulate) acc += out[i];
     out[i] = acc;
   }
+}
+
+// several independent folds, one launch: block -> job by the jobs' first-block numbers
+__global__ __launch_bounds__(256) void k_fold_jobs(const FoldJobs J) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int jn = 0;
+#pragma unroll
+  for (int q = 1; q < FoldJobs::MAX; ++q)
+    if (q < J.n && (int)blockIdx.x >= J.j[q].blk0) jn = q;
+  const float* src = J.j[0].src; float* dst = J.j[0].dst; long stride = J.j[0].stride; int len = J.j[0].len, S = J.j[0].S, b0 = 0;
+#pragma unroll
+  for (int q = 1; q < FoldJobs::MAX; ++q)          // (selects instead of a dynamically indexed kernel argument)
+    if (q == jn) { src = J.j[q].src; dst = J.j[q].dst; stride = J.j[q].stride; len = J.j[q].len; S = J.j[q].S; b0 = J.j[q].blk0; }
+  const long i = (long)((int)blockIdx.x - b0) * 64 + tx;
+  float acc = i < len ? slab_partial(src, i, S, stride, ty) : 0.f;
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < len) dst[i] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+int fold_jobs(FoldJobs& jobs, hipStream_t st) {
+  if (jobs.n == 0) return RPDE_OK;
+  int blocks = 0;
+  for (int q = 0; q < jobs.n; ++q) { jobs.j[q].blk0 = blocks; blocks += (jobs.j[q].len + 63) / 64; }
+  hipLaunchKernelGGL(k_fold_jobs, dim3((unsigned)blocks), dim3(256), 0, st, jobs);
+  RPDE_LAUNCH_CHECK();
+  jobs.n = 0;
+  return RPDE_OK;
 }
 
 int reduce_slabs(const float* slabs, float* out, long n, int S, long stride, float scale, int accumulate, hipStream_t st) {
@@ -452,8 +486,13 @@ size_t ff_tail_bwd_ws_floats(long P, int C) { return (size_t)tail_bwd_blocks(P) 
 // grad_bias (optional) receives colsum(dz) when the vector kernel runs; returns whether it did
 int ff_tail_bwd(const float* z, const float* g, float* dz, long P, int C, int layer_norm, float eps, const float* gamma,
                 const float* beta, DropCfg drop, int post_act, float* grad_gamma, float* grad_beta, float* grad_bias,
-                int* bias_done, float* ws, hipStream_t st) {
+                int* bias_done, float* ws, hipStream_t st, FoldJobs* defer) {
   *bias_done = 0;
+  // the per-block partial sums are folded here, or (defer) by the caller's one fold launch -- same sums
+  auto fold = [&](const float* src, float* dst, int S, long stride) -> int {
+    if (defer && defer->add(src, dst, C, S, stride)) return RPDE_OK;
+    return reduce_slabs(src, dst, C, S, stride, 1.f, 0, st);
+  };
   if (tail_vec_ok(C)) {
     const int G = C / 4;
     const long rpb = 256 / G;
@@ -467,10 +506,10 @@ int ff_tail_bwd(const float* z, const float* g, float* dz, long P, int C, int la
 #undef LAUNCH_G
     RPDE_LAUNCH_CHECK();
     if (layer_norm) {
-      if (grad_gamma) RPDE_TRY(reduce_slabs(ws, grad_gamma, C, (int)nb, 3L * C, 1.f, 0, st));
-      if (grad_beta) RPDE_TRY(reduce_slabs(ws + C, grad_beta, C, (int)nb, 3L * C, 1.f, 0, st));
+      if (grad_gamma) RPDE_TRY(fold(ws, grad_gamma, (int)nb, 3L * C));
+      if (grad_beta) RPDE_TRY(fold(ws + C, grad_beta, (int)nb, 3L * C));
     }
-    if (grad_bias) { RPDE_TRY(reduce_slabs(ws + 2 * C, grad_bias, C, (int)nb, 3L * C, 1.f, 0, st)); *bias_done = 1; }
+    if (grad_bias) { RPDE_TRY(fold(ws + 2 * C, grad_bias, (int)nb, 3L * C)); *bias_done = 1; }
     return RPDE_OK;
   }
   RPDE_CHECK_ARG(C <= 512, "ff_tail_bwd: width %d > 512 unsupported", C);
@@ -478,8 +517,8 @@ int ff_tail_bwd(const float* z, const float* g, float* dz, long P, int C, int la
   hipLaunchKernelGGL(k_ff_tail_bwd, dim3((unsigned)nb), dim3(256), 0, st, z, g, dz, ws, P, C, layer_norm, eps, gamma, beta, drop, post_act);
   RPDE_LAUNCH_CHECK();
   if (layer_norm) {
-    if (grad_gamma) RPDE_TRY(reduce_slabs(ws, grad_gamma, C, (int)nb, 2L * C, 1.f, 0, st));
-    if (grad_beta) RPDE_TRY(reduce_slabs(ws + C, grad_beta, C, (int)nb, 2L * C, 1.f, 0, st));
+    if (grad_gamma) RPDE_TRY(fold(ws, grad_gamma, (int)nb, 2L * C));
+    if (grad_beta) RPDE_TRY(fold(ws + C, grad_beta, (int)nb, 2L * C));
   }
   return RPDE_OK;
 }
@@ -536,6 +575,41 @@ int unpack_mix_grad(const float* slabs, float* gw, int Ci, int Co, int K, int ke
   hipLaunchKernelGGL(k_unpack_mix_grad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, gw, Ci, Co, K, keff, S, sstride);
   RPDE_LAUNCH_CHECK();
   return RPDE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// weight normalisation of WNLinear (models/custom_layer.py:70-108; torch.nn.utils.weight_norm, dim 0):
+//   w[o,:] = v[o,:] * (g[o] / |v[o,:]|)
+//   gg[o]  = <gw[o,:], v[o,:]> / |v[o,:]|
+//   gv[o,:] = (g[o] / |v[o,:]|) * (gw[o,:] - v[o,:] * <gw[o,:], v[o,:]> / |v[o,:]|^2)
+// one wave per row (the reference's graph is a dozen ATen kernels on [128,1] / [1,128] tensors per step)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_weight_norm_fwd(const float* __restrict__ v, const float* __restrict__ g,
+                                                         float* __restrict__ w, int out_f, int in_f) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= out_f) return;
+  const float* vr = v + (long)o * in_f;
+  float ss = 0.f;
+  for (int i = lane; i < in_f; i += 64) ss = fmaf(vr[i], vr[i], ss);
+  const float scale = g[o] / sqrtf(wave_sum(ss));
+  for (int i = lane; i < in_f; i += 64) w[(long)o * in_f + i] = vr[i] * scale;
+}
+
+__global__ __launch_bounds__(256) void k_weight_norm_bwd(const float* __restrict__ v, const float* __restrict__ g,
+                                                         const float* __restrict__ gw, float* __restrict__ gv,
+                                                         float* __restrict__ gg, int out_f, int in_f) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= out_f) return;
+  const float* vr = v + (long)o * in_f;
+  const float* gr = gw + (long)o * in_f;
+  float ss = 0.f, dot = 0.f;
+  for (int i = lane; i < in_f; i += 64) { ss = fmaf(vr[i], vr[i], ss); dot = fmaf(gr[i], vr[i], dot); }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  const float nrm = sqrtf(ss), scale = g[o] / nrm, back = dot / ss;
+  if (gg && lane == 0) gg[o] = dot / nrm;
+  if (gv)
+    for (int i = lane; i < in_f; i += 64) gv[(long)o * in_f + i] = scale * (gr[i] - vr[i] * back);
 }
 
 // ---------------------------------------------------------------------------
@@ -620,6 +694,22 @@ __global__ __launch_bounds__(256) void k_rel_l2_bwd(const float* __restrict__ x,
 using namespace rpde;
 
 extern "C" {
+
+int rpde_weight_norm_fwd(const float* v, const float* g, float* w, int out_f, int in_f, void* stream) {
+  RPDE_CHECK_ARG(v && g && w && out_f > 0 && in_f > 0, "weight_norm_fwd: bad arguments");
+  hipLaunchKernelGGL(k_weight_norm_fwd, dim3((out_f + 3) / 4), dim3(256), 0, as_stream(stream), v, g, w, out_f, in_f);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
+int rpde_weight_norm_bwd(const float* v, const float* g, const float* grad_w, float* grad_v, float* grad_g, int out_f, int in_f,
+                         void* stream) {
+  RPDE_CHECK_ARG(v && g && grad_w && (grad_v || grad_g) && out_f > 0 && in_f > 0, "weight_norm_bwd: bad arguments");
+  hipLaunchKernelGGL(k_weight_norm_bwd, dim3((out_f + 3) / 4), dim3(256), 0, as_stream(stream), v, g, grad_w, grad_v, grad_g, out_f, in_f);
+  RPDE_LAUNCH_CHECK();
+  return RPDE_OK;
+}
+
 
 int rpde_rel_l2_fwd(const float* x, const float* y, float* rel, float* loss, float* stats, int B, int64_t per,
                     int size_average, void* stream) {

@@ -174,6 +174,16 @@ int launch_gemm(const rpde_gemm_desc& d, hipStream_t stream);
 int split_npad(int N);
 size_t split_bytes(int N, int K);
 int split_weights(const float* w, int kmajor, long ld, int N, int K, void* out, hipStream_t st);
+struct SplitJobs {
+  static constexpr int MAX = 4;
+  int n = 0;
+  struct Job { const float* w; char* out; long ld; int kmajor, N, K, blk0; } j[MAX];
+  void add(const float* w, int kmajor, long ld, int N, int K, void* out) {
+    j[n].w = w; j[n].out = static_cast<char*>(out); j[n].ld = ld; j[n].kmajor = kmajor; j[n].N = N; j[n].K = K; j[n].blk0 = 0;
+    ++n;
+  }
+};
+int split_weights_multi(SplitJobs& J, hipStream_t st);
 
 inline rpde_gemm_desc gemm_desc() {
   rpde_gemm_desc d;

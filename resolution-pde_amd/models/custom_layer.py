@@ -93,7 +93,9 @@ class WNLinear(nn.Linear):
         if not self.wnorm:
             return self.weight
         v = self.weight_v
-        return v * (self.weight_g / v.norm(2, dim=1, keepdim=True))
+        if v.is_cuda and v.dtype == torch.float32:
+            return ops.weight_norm(v, self.weight_g)
+        return v * (self.weight_g / v.norm(2, dim=1, keepdim=True))       # parameter bookkeeping on the host only
 
     def __getattr__(self, name):
         if name == "weight" and "weight_v" in self.__dict__.get("_parameters", {}):

@@ -106,6 +106,8 @@ _SIGNATURES = {
     "rpde_fno2d_lift_block_eval_ok": (_I, [_I] * 7),
     "rpde_fno2d_lift_block_eval_fwd": (_I, [_P] * 10 + [_I] * 8 + [_P, _Z, _P]),
     "rpde_linear_ws_bytes": (_Z, [_L, _I, _I]),
+    "rpde_weight_norm_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "rpde_weight_norm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "rpde_linear_fwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
     "rpde_linear_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _Z, _P]),
     "rpde_conv1x1_ws_bytes": (_Z, [_I, _I, _I, _L]),

@@ -391,6 +391,37 @@ def linear(x, w, b=None):
     return _Linear.apply(x, w, b)
 
 
+class _WeightNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, g):
+        lib = load()
+        v = _f32c(v)
+        g = _f32c(g)
+        out_f, in_f = v.shape
+        w = torch.empty_like(v)
+        check(lib.rpde_weight_norm_fwd(ptr(v), ptr(g), ptr(w), out_f, in_f, stream_ptr()), "weight_norm_fwd")
+        ctx.save_for_backward(v, g)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        lib = load()
+        v, g = ctx.saved_tensors
+        out_f, in_f = v.shape
+        gw = _f32c(gw)
+        gv = torch.empty_like(v) if ctx.needs_input_grad[0] else None
+        gg = torch.empty_like(g) if ctx.needs_input_grad[1] else None
+        if gv is None and gg is None:
+            return None, None
+        check(lib.rpde_weight_norm_bwd(ptr(v), ptr(g), ptr(gw), ptr(gv), ptr(gg), out_f, in_f, stream_ptr()), "weight_norm_bwd")
+        return gv, gg
+
+
+def weight_norm(v, g):
+    """WNLinear's effective weight v * (g / |v|_row) (models/custom_layer.py:70-108), v [out,in], g [out,1]"""
+    return _WeightNorm.apply(v, g)
+
+
 # ----------------------------------------------------------------------------
 # FNO: channels-first spectral conv, 1x1 conv, activation
 # ----------------------------------------------------------------------------

@@ -499,3 +499,54 @@ def test_fused_evaluation_fnoblock2d_equals_the_two_step_path(gpu_device, shape,
                 os.environ["RPDE_CONV_SYN_H2"] = old
     rows = (a - b_).flatten(0, 1).transpose(0, 1).flatten(1).norm(dim=1) / b_.flatten(0, 1).transpose(0, 1).flatten(1).norm(dim=1).clamp_min(1e-30)
     assert float(rows.max()) < 5e-6, float(rows.max())
+
+
+@pytest.mark.parametrize("B,n,C,K", [(16, 512, 128, 64), (4, 512, 128, 64), (1, 64, 32, 9), (17, 48, 64, 30),
+                                     (40, 32, 32, 64), (64, 100, 64, 21), (3, 24, 128, 5)])
+def test_few_row_mode_mix_reads_the_weights_in_place(gpu_device, B, n, C, K):
+    """mix1d.hip (k_mix1d / k_mix1d_wgrad): the 1-D layer's per-mode channel mixing without the [k][2C][2C] weight
+    repack -- forward, data gradient and weight gradient against the float64 restatement of
+    models/spectral_convolution.py:158-204 (row tiles of 16 incl. partial ones, mode counts that are no multiple of 8
+    or of 4, modes clamped at n/2+1: the unused weight slices must get a zero gradient)."""
+    from oracle import reference_path as R
+    from rpde import ops
+    torch.manual_seed(B * 1000 + C + K)
+    x = torch.randn(B, n, C, device=gpu_device, requires_grad=True)
+    w = (torch.randn(C, C, K, 2, device=gpu_device) / C ** 0.5).requires_grad_()
+    probe = torch.randn(B, n, C, device=gpu_device)
+    out = ops.fspectral1d(x, w, K)
+    (out * probe).sum().backward()
+    xd = x.detach().double().cpu().requires_grad_()
+    wd = w.detach().double().cpu().requires_grad_()
+    ref = R.fspectral1d_fourier(xd, wd, K)
+    (ref * probe.double().cpu()).sum().backward()
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30))
+
+    assert rel(out.detach(), ref.detach()) < 2e-6
+    assert rel(x.grad, xd.grad) < 2e-6
+    assert rel(w.grad, wd.grad) < 2e-6
+    keff = min(K, n // 2 + 1)
+    assert not w.grad[:, :, keff:].any()
+
+
+@pytest.mark.parametrize("out_f,in_f", [(128, 1), (1, 128), (64, 64), (5, 200), (33, 7)])
+def test_weight_norm_kernels_match_autograd(gpu_device, out_f, in_f):
+    """rpde_weight_norm_fwd / _bwd against the expression the reference's WNLinear evaluates
+    (models/custom_layer.py:70-108: torch.nn.utils.weight_norm, w = v * (g / |v|_row)) and its autograd gradient."""
+    from rpde import ops
+    torch.manual_seed(out_f * 7 + in_f)
+    v = torch.randn(out_f, in_f, device=gpu_device, requires_grad=True)
+    g = (torch.rand(out_f, 1, device=gpu_device) + 0.5).requires_grad_()
+    probe = torch.randn(out_f, in_f, device=gpu_device)
+    w = ops.weight_norm(v, g)
+    (w * probe).sum().backward()
+    vd, gd = v.detach().double().requires_grad_(), g.detach().double().requires_grad_()
+    wd = vd * (gd / vd.norm(2, dim=1, keepdim=True))
+    (wd * probe.double()).sum().backward()
+    assert float((w.detach().double() - wd.detach()).abs().max()) < 1e-6 * float(wd.detach().abs().max())
+    # (with one input feature the gradient of v cancels exactly in exact arithmetic: measure against the terms' size)
+    size = float((gd.detach() / vd.detach().norm(2, dim=1, keepdim=True) * probe.double()).norm())
+    assert float((v.grad.double() - vd.grad).norm()) <= 2e-6 * size
+    assert float((g.grad.double() - gd.grad).norm()) <= 2e-6 * float(probe.double().norm())
