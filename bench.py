@@ -299,7 +299,7 @@ def mres_leg(model, bucket, opt, loss_fn, B, world, rank, device, batches_per_re
     (the reference's train/mres_training.py:87-166 with a seed and rank slices), from page-locked host memory with the
     host-to-device copies inside the timed region (non_blocking, one batch ahead on a side stream).  Every rank builds
     the same dataset and takes its slice of each global batch, so all ranks run the same resolution in the same step.
-    Epoch 0 is the warm-up (DFT plans and allocator pools of the three grids), epoch 1 is timed."""
+    Epochs 0 and 1 are the warm-up (DFT plans and allocator pools of the three grids), epochs 2 and 3 are timed."""
     from train.mres_training import ResolutionGroupedDataLoader, SimpleDataset
     from utils.synthetic import markov_pairs
     per_res = batches_per_res * B * world
@@ -320,11 +320,14 @@ def mres_leg(model, bucket, opt, loss_fn, B, world, rank, device, batches_per_re
             ready.record(copy_stream)
         return xd, yd, ready
 
+    host = []
+
     def epoch(events):
         it = iter(loader)
         nxt = fetch(it)
         n = 0
         while nxt is not None:
+            h0 = time.perf_counter()
             xd, yd, ready = nxt
             main_stream.wait_event(ready)
             xd.record_stream(main_stream)
@@ -334,7 +337,10 @@ def mres_leg(model, bucket, opt, loss_fn, B, world, rank, device, batches_per_re
             bucket.all_reduce_mean()
             bucket.detach_untouched()
             opt.step()
+            h1 = time.perf_counter()
             nxt = fetch(it)                          # host: stack the next batch + start its copies while the GPU runs this step
+            if events is not None:
+                host.append([int(xd.shape[-1]), round((h1 - h0) * 1e3, 2), round((time.perf_counter() - h1) * 1e3, 2)])
             if events is not None:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
@@ -342,6 +348,9 @@ def mres_leg(model, bucket, opt, loss_fn, B, world, rank, device, batches_per_re
             n += 1
         return n
 
+    # two warm-up epochs: the caching allocator still asks the driver for new segments in the second one (every epoch
+    # draws another batch order; a segment request stalls the GPU for ~100 ms -- profiles/mres_host_probe.py)
+    epoch(None)
     epoch(None)
     if world > 1:
         dist.barrier()
@@ -350,7 +359,7 @@ def mres_leg(model, bucket, opt, loss_fn, B, world, rank, device, batches_per_re
     events = []
     t0 = time.perf_counter()
     e0.record()
-    steps = epoch(events)
+    steps = epoch(events) + epoch(events)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -366,10 +375,11 @@ def mres_leg(model, bucket, opt, loss_fn, B, world, rank, device, batches_per_re
     return {"workload": "FFNO2D cfg3 on a ResolutionGroupedDataLoader stream {64,128,256}^2 in equal thirds (BASELINE configs[3]), "
                         "pinned host batches, H2D inside the timed region",
             "value": round(steps * B * world / elapsed, 2), "unit": "samples/s", "steps": steps, "batch_per_gpu": B,
-            "batches_per_resolution": batches_per_res, "ms_per_epoch": round(elapsed * 1e3, 3),
+            "batches_per_resolution": batches_per_res, "epochs": 2, "ms_per_epoch": round(elapsed * 1e3 / 2, 3),
             "ms_per_step_by_resolution": {str(r): round(sorted(v)[len(v) // 2], 3) for r, v in sorted(by_res.items())},
             "ms_all_steps_in_order": [[r, round(prev_e.elapsed_time(e), 3)] for (r, e), prev_e in
-                                      zip(events, [e0] + [e for _, e in events[:-1]])]}
+                                      zip(events, [e0] + [e for _, e in events[:-1]])],
+            "host_ms_in_order": host, "host_ms_what": "[resolution, host time to launch the step, host time to draw + copy-start the next batch]"}
 
 
 def graph_leg(model, bucket, opt, loss_fn, x, y, world, device, steps):
@@ -403,15 +413,8 @@ def graph_leg(model, bucket, opt, loss_fn, x, y, world, device, steps):
 
 
 def host_cores() -> int:
-    """cores this process may really use: affinity mask, capped by the cgroup CPU quota"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return max(1, min(n, int(os.environ.get("RPDE_CPU_THREADS", "64"))))
+    from rpde.launch import host_cores as _hc
+    return _hc()
 
 
 def _cpu_steps(batch, warm, timed, threads):
@@ -529,6 +532,8 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
+    from rpde.launch import limit_host_threads
+    limit_host_threads(world)                  # torch's intra-op pool: this rank's share of the cores it may really use
 
     from models.ffno import FFNO2D
     from rpde.parallel import FlatGradBucket

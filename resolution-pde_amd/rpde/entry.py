@@ -42,6 +42,8 @@ def run(dims: int, argv=None):
     world, rank, local = _init_distributed()
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
+    from rpde.launch import limit_host_threads
+    limit_host_threads(world)                  # host ops (batch stacking, pinned copies) on the cores this rank may use
 
     from train.mres_training import ResolutionGroupedDataLoader
     from train.training import evaluate, train

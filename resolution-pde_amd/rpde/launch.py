@@ -64,3 +64,29 @@ def spawn_ranks(script: str, argv: Sequence[str], world: int, poll_s: float = 0.
             except subprocess.TimeoutExpired:
                 p.kill()
     return rc
+
+
+def host_cores() -> int:
+    """cores this process may really use: affinity mask, capped by the cgroup CPU quota (and RPDE_CPU_THREADS)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("RPDE_CPU_THREADS", "64"))))
+
+
+def limit_host_threads(world: int = 1) -> int:
+    """torch sizes its intra-op pool by the machine's logical CPUs (256 on an MI355X host) even when the process may use
+    16 of them (a container's CPU quota): every multi-threaded host op -- stacking a batch, a copy into a pinned buffer --
+    then wakes hundreds of threads on a handful of cores and the launching thread loses 50-100 ms at a time, during which
+    the GPU runs dry (profiles/mres_host_probe.py: mixed-resolution epochs of 237-277 ms against 173 ms).  One process
+    per GPU: each gets its share of the usable cores.  Returns the thread count set."""
+    import torch
+    n = max(1, host_cores() // max(1, int(world)))
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()

@@ -145,9 +145,10 @@ class ResolutionGroupedDataLoader:
                 if buf is None or buf.shape[0] < len(parts) or buf.shape[1:] != parts[0].shape or buf.dtype != parts[0].dtype:
                     buf = torch.empty((self.batch_size,) + tuple(parts[0].shape), dtype=parts[0].dtype).pin_memory()
                     self._pinned[key] = buf
-                # (sample by sample: torch.stack(..., out=) into a preallocated buffer takes ~50 ms for 32 fields of 256^2 once
-                #  torch runs its copy kernel multi-threaded, against ~1 ms this way -- it starved the GPU in front of small-grid
-                #  steps)
+                # (sample by sample: torch.stack(..., out=) into a preallocated buffer took ~50 ms for 32 fields of 256^2
+                #  against ~1 ms this way.  Root cause, found later: torch's intra-op pool is sized by the host's 256 logical
+                #  CPUs inside a 16-core quota -- rpde.launch.limit_host_threads(), called by the entry points, fixes that
+                #  for every host op; the small copies stay, they never wake the pool)
                 view = buf[:len(parts)]
                 for i, part in enumerate(parts):
                     view[i].copy_(part)
