@@ -8,6 +8,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "resolution-pde_amd"))
 import torch  # noqa: E402
+from rpde.launch import limit_host_threads  # noqa: E402
+limit_host_threads()                      # the eager legs are host-bound: no oversubscribed thread pool beside them
 import bench  # noqa: E402
 from models.ffno import FFNO2D  # noqa: E402
 from utils.loss import RelativeL2Loss  # noqa: E402

@@ -11,6 +11,8 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "resolution-pde_amd"))
 import torch  # noqa: E402
+from rpde.launch import limit_host_threads  # noqa: E402
+limit_host_threads()                      # the eager legs are host-bound: no oversubscribed thread pool beside them
 from models.ffno import FFNO1D  # noqa: E402
 from models.fno import FNO1d, FNO2d  # noqa: E402
 from utils.loss import RelativeL2Loss  # noqa: E402
