@@ -227,6 +227,53 @@ def time_cfg5(device, B=8, iters=10):
     return ms, 67.11e6 * B + 2.36e6, ms_model, ms_model16
 
 
+def time_shipped_yamls(B, device):
+    """The reference's SHIPPED model yamls beside the BASELINE configurations (they differ: conf/model/ffno_2d/ffno_2d.yaml
+    has n_modes 64, which is off the fused spectral path; conf/model/ffno_1d/ffno_1d.yaml is BASELINE configs[1]'s model):
+      * one FSpectralConv2d.forward_fourier at K = 64, [B,256,256,64] (pack + per-mode GEMM + unpack around truncated-DFT
+        GEMMs) and the FFNO2D(n_modes 64, dropout 0.1) training step at batch B;
+      * FFNO1D(width 128, 64 modes, 3 FeedForward layers, LayerNorm, dropout 0.2) training step at [16,1,512], eager and as
+        one hipGraph replay (the configuration is launch-bound)."""
+    from models.ffno import FFNO1D, FFNO2D
+    from rpde import ops
+    from rpde.graph import GraphedTrainStep
+    from rpde.optim import FlatAdamW
+    from utils.loss import RelativeL2Loss
+    K = 64
+    g = torch.Generator(device="cpu").manual_seed(23)
+    x = torch.randn(B, RES, RES, 64, generator=g).to(device)
+    wy = (torch.randn(64, 64, K, 2, generator=g) * 0.1).to(device)
+    wx = (torch.randn(64, 64, K, 2, generator=g) * 0.1).to(device)
+    with torch.no_grad():
+        spec_ms = _ev_time(lambda: ops.fspectral2d(x, wy, wx, K), 10)
+    del x
+    loss_fn = RelativeL2Loss(size_average=True)
+
+    def stepper(model, xb, yb, opt):
+        def step():
+            opt.zero_grad()
+            loss_fn(model(xb), yb).backward()
+            opt.step()
+        return step
+    torch.manual_seed(0)
+    m2 = FFNO2D(**dict(CFG3, n_modes=K)).to(device).train()
+    xb = torch.randn(B, 1, RES, RES, generator=g).to(device)
+    yb = torch.randn(B, 1, RES, RES, generator=g).to(device)
+    step2_ms = _ev_time(stepper(m2, xb, yb, FlatAdamW(m2.parameters(), lr=1e-3)), 5, warm=2)
+    del m2, xb, yb
+    torch.manual_seed(0)
+    m1 = FFNO1D(1, 1, width=128, n_layers=4, n_modes=64, factor=4, ff_weight_norm=True, n_ff_layers=3, layer_norm=True,
+                dropout=0.2).to(device).train()
+    x1 = torch.randn(16, 1, 512, generator=g).to(device)
+    y1 = torch.randn(16, 1, 512, generator=g).to(device)
+    opt1 = FlatAdamW(m1.parameters(), lr=1e-3, capturable=True)
+    eager1_ms = _ev_time(stepper(m1, x1, y1, opt1), 30, warm=5)
+    gstep = GraphedTrainStep(m1, loss_fn, opt1, x1, y1)
+    graph1_ms = _ev_time(lambda: gstep(x1, y1), 50, warm=5)
+    return {"spec_ms": spec_ms, "spec_bytes": 4.0 * B * RES * RES * 2 * 64 + 2 * 8.0 * 64 * 64 * K, "step2_ms": step2_ms,
+            "ffno1d_eager_ms": eager1_ms, "ffno1d_graph_ms": graph1_ms}
+
+
 def gpu_aten_baseline(B, device, hip_spec_ms, hip_spec_fb_ms, hip_ff_fwd_ms, hip_ff_fb_ms, hip_step_ms):
     """The reference's own op sequence on this GPU through stock ATen (hipFFT/rocFFT for rfft/irfft, hipBLASLt/rocBLAS
     for einsum/linear): oracle/reference_path.py on cuda tensors.  Baseline leg only (like cpu_baseline); the product
@@ -572,6 +619,8 @@ def main():
         step(i)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
+    from rpde.launch import freeze_setup_garbage
+    freeze_setup_garbage()                     # no full garbage collection over the setup's objects inside a timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -618,6 +667,9 @@ def main():
         c5_ms, c5_bytes, c5_model_ms, c5_model16_ms = time_cfg5(device)
         log(f"config 5: SpectralConv2d 512^2 forward {c5_ms:.3f} ms, FNO2d eval forward {c5_model_ms:.3f} ms (B=8), "
             f"{c5_model16_ms:.3f} ms (B=16)")
+        sy = time_shipped_yamls(B, device)
+        log(f"shipped yamls: FFNO2D n_modes 64: layer forward {sy['spec_ms']:.3f} ms, step {sy['step2_ms']:.3f} ms; FFNO1D step "
+            f"{sy['ffno1d_eager_ms']:.3f} ms eager, {sy['ffno1d_graph_ms']:.3f} ms as a hipGraph")
         traffic = step_traffic = traffic_src = spec_traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -693,7 +745,16 @@ def main():
                 hbm("BASELINE config 5: FNO2d(1,1,12,12,32) evaluation forward at [16,1,512,512] (per block: k_cf_analysis_h2, two row "
                     "DFTs + mode mix on the small spectra, then ONE pass for inverse DFT + bypass conv + GELU; fused projection MLP)",
                     16 * 337.6e6, c5_model16_ms, samples_per_s=round(16 / c5_model16_ms * 1e3, 1)),
+                hbm("the reference's SHIPPED ffno_2d.yaml (n_modes 64, off the fused spectral path): FSpectralConv2d.forward_fourier "
+                    f"at [{B},256,256,64], K = 64 (truncated-DFT GEMMs + per-mode GEMM), SURVEY 8(d) bytes", sy["spec_bytes"], sy["spec_ms"],
+                    ffno2d_n_modes64_train_step_ms=round(sy["step2_ms"], 3),
+                    ffno2d_n_modes64_samples_per_s=round(B / sy["step2_ms"] * 1e3, 1)),
             ],
+            "config2_ffno1d": {"workload": "BASELINE configs[1] with the reference's ffno_1d.yaml: FFNO1D(width 128, 4 layers, 64 modes, "
+                               "3-layer FeedForward, LayerNorm, weight norm, dropout 0.2) training step at [16,1,512]",
+                               "eager_ms_per_step": round(sy["ffno1d_eager_ms"], 3), "graphed_ms_per_step": round(sy["ffno1d_graph_ms"], 3),
+                               "samples_per_s_graphed": round(16 / sy["ffno1d_graph_ms"] * 1e3, 1),
+                               "note": "launch-bound: ~100 dispatches per step (profiles/r04_ffno1d_sequence_after.txt)"},
             "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_mix_prep + k_dft_analysis_rr_h2 (both axes, the field read "
                                      "from HBM once, no cross-wave sums) + k_mix_h2 (mode mix of both axes, writes the synthesis "
                                      "operands) + k_dft_synthesis4_h2 (field written once, whole 128-byte lines)",

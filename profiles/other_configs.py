@@ -113,6 +113,15 @@ for B in (16, 256):
     mg = timed(graphed(m, x, torch.randn_like(x)))
     print(f"cfg1 FFNO1D 512 train  B={B:4d}: {ms:8.3f} ms/step  {B / ms * 1e3:10.0f} samples/s | hipGraph {mg:8.3f} ms/step "
           f"{B / mg * 1e3:10.0f} samples/s", flush=True)
+# the same model with the reference's yaml settings (conf/model/ffno_1d/ffno_1d.yaml: 3 FeedForward layers, LayerNorm, dropout 0.2)
+m = FFNO1D(1, 1, width=128, n_layers=4, n_modes=64, factor=4, ff_weight_norm=True, n_ff_layers=3, layer_norm=True,
+           dropout=0.2).to(dev).train()
+for B in (16,):
+    x = torch.randn(B, 1, 512, device=dev)
+    ms = timed(train_step(m, x, torch.randn_like(x)))
+    mg = timed(graphed(m, x, torch.randn_like(x)))
+    print(f"cfg1 FFNO1D 512 yaml   B={B:4d}: {ms:8.3f} ms/step  {B / ms * 1e3:10.0f} samples/s | hipGraph {mg:8.3f} ms/step "
+          f"{B / mg * 1e3:10.0f} samples/s   (ffno_1d.yaml: 3 FeedForward layers, LayerNorm, dropout 0.2)", flush=True)
 m = FNO2d(1, 1, modes1=12, modes2=12, width=32).to(dev).eval()
 for B in (4, 16):
     x = torch.randn(B, 1, 512, 512, device=dev)

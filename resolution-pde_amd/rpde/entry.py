@@ -107,6 +107,8 @@ def run(dims: int, argv=None):
     if rank == 0:
         print(json.dumps({"model": args.model["_target_"], "params": n_params, "world": world,
                           "train_batches": len(train_loader), "choices": args["_choices_"]}), flush=True)
+    from rpde.launch import freeze_setup_garbage
+    freeze_setup_garbage()                     # model, optimizer, datasets are long-lived: keep full collections off them
     t0 = time.time()
     loss_hist, val_hist = train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=y_normalizer,
                                 use_normalizer=bool(args.training.use_normalizer), epochs=int(args.training.epochs),

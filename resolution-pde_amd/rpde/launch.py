@@ -90,3 +90,13 @@ def limit_host_threads(world: int = 1) -> int:
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     return torch.get_num_threads()
+
+
+def freeze_setup_garbage() -> None:
+    """call once the model, the optimizer and the loaders exist: a full (generation-2) collection of a process that has
+    imported torch walks ~10^6 objects -- 80-160 ms on these hosts (profiles/mres_host_probe.py), during which nothing is
+    launched; a 3 ms step's queue runs dry.  Everything alive now is long-lived: collect once, then move it to the
+    permanent generation so that later collections only look at what the steps create."""
+    import gc
+    gc.collect()
+    gc.freeze()
