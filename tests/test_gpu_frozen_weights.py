@@ -100,3 +100,20 @@ def test_rollout_and_sweep_use_the_scope(gpu_device, monkeypatch):
     # the same rollout without the scope
     monkeypatch.setattr(ops, "_frozen_entry", lambda *a, **k: None)
     assert torch.equal(perform_rollout_2d(model, x0, steps, device=gpu_device), preds)
+
+
+def test_eight_layer_model_runs_every_layer_on_the_fused_kernels(gpu_device):
+    """`n_layers: 8` (the reference yaml's other setting, conf/model/ffno_2d/ffno_2d.yaml:7) changes how often the layer
+    kernels run, not which ones: every layer of an 8-layer FFNO2D prepares one fused spectral pair and one fused
+    FeedForward (a shape on the per-GEMM path prepares nothing)."""
+    from rpde import ops
+    from utils.synthetic import random_fields
+    model = _model(gpu_device, n_layers=8)
+    x = random_fields(2, 64, 2, seed=9).to(gpu_device)
+    lib = ops.load()
+    assert lib.rpde_feedforward_is_fused(64, 4, 3, 2 * 64 * 64) == 1
+    with torch.no_grad(), ops.frozen_weights():
+        y = model(x)
+        kinds = sorted(k[0] if isinstance(k, tuple) else k for k in ops._FROZEN)
+    assert torch.isfinite(y).all()
+    assert len(kinds) >= 16, kinds
