@@ -642,6 +642,39 @@ def main():
     ar_ms = sum(a.elapsed_time(b) for a, b in ar_ev) / len(ar_ev) if world > 1 else 0.0
     lh = losses.cpu().tolist()
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps; rel-L2 {lh[0]:.4f} -> {lh[-1]:.4f}")
+    # FSpectralConv2d.forward_fourier timed WHERE IT RUNS: four more training steps (every rank: the all-reduce is in the
+    # step) with an event pair around each of the layer's forward calls.  The stand-alone loop of time_spectral() runs
+    # the same four launches back to back, and every one of them slows by 10-20 % within its first 5 ms (the clock
+    # settling under sustained matrix + memory load); inside a step they run at the step's clock.
+    spec_in_step = ff_in_step = None
+    if not args.steps_only:
+        from rpde import ops as _ops
+        pairs = {"fspectral2d": [], "feedforward": []}
+        real = {k: getattr(_ops, k) for k in pairs}
+
+        def timed_call(name):
+            def call(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = real[name](*a, **k)
+                e1.record()
+                pairs[name].append((e0, e1))
+                return r
+            return call
+        for name in pairs:
+            setattr(_ops, name, timed_call(name))
+        try:
+            for _ in range(4):
+                step(args.warmup + args.steps - 1)
+        finally:
+            for name in pairs:
+                setattr(_ops, name, real[name])
+        torch.cuda.synchronize()
+        mean = lambda ps: sum(a.elapsed_time(b) for a, b in ps) / len(ps)      # noqa: E731
+        spec_in_step, ff_in_step = mean(pairs["fspectral2d"]), mean(pairs["feedforward"])
+        log(f"FeedForward forward (training) inside the training step: {ff_in_step:.4f} ms (mean of {len(pairs['feedforward'])} calls)")
+        pairs = pairs["fspectral2d"]
+        log(f"spectral forward inside the training step: {spec_in_step:.4f} ms (mean of {len(pairs)} calls)")
     graphed = None
     # (at N > 1 only on request: a capture that RCCL refused on one box would hang the other ranks, and N > 1 cannot be
     #  rehearsed on the 1-GPU boxes this is built on -- tests/test_gpu_rccl.py captures the collective in a world of one)
@@ -690,6 +723,7 @@ def main():
             return d
 
         tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 2)                                  # noqa: E731
+        ff_ms = ff_in_step if ff_in_step else ff["fwd_train_ms"]
         line = {
             "metric": "training samples/sec, FFNO2D NS 256^2", "value": round(value, 3), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -711,13 +745,18 @@ def main():
             # matrix pipe executes 3x that: achieved = issued flops / time, peak = 2.5 PFLOP/s dense f16
             "roofline": {"kernel": "k_ff3_fwd_h2<train>: fused FeedForward 64->256->256->64 forward of one layer (+ its weight "
                                    "preparation launch)",
-                         "bound": "mfma", "achieved": tf(3.0 * ff["flops_fwd"], ff["fwd_train_ms"]), "peak": PEAK_BF16_MFMA_TF,
-                         "unit": "TFLOP/s", "frac": round(tf(3.0 * ff["flops_fwd"], ff["fwd_train_ms"]) / PEAK_BF16_MFMA_TF, 4),
+                         "bound": "mfma", "achieved": tf(3.0 * ff["flops_fwd"], ff_ms), "peak": PEAK_BF16_MFMA_TF,
+                         "unit": "TFLOP/s", "frac": round(tf(3.0 * ff["flops_fwd"], ff_ms) / PEAK_BF16_MFMA_TF, 4),
                          "flops_per_launch": ff["flops_fwd"], "issued_flops_per_launch": 3.0 * ff["flops_fwd"],
                          "issued_flops": "3x: a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_16x16x32_f16, fp32 accumulate",
-                         "fp32_equiv_tflops": tf(ff["flops_fwd"], ff["fwd_train_ms"]),
-                         "frac_of_fp32_mfma_peak": round(tf(ff["flops_fwd"], ff["fwd_train_ms"]) / PEAK_F32_MFMA_TF, 4),
-                         "ms_per_launch": round(ff["fwd_train_ms"], 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "fp32_equiv_tflops": tf(ff["flops_fwd"], ff_ms),
+                         "frac_of_fp32_mfma_peak": round(tf(ff["flops_fwd"], ff_ms) / PEAK_F32_MFMA_TF, 4),
+                         "ms_per_launch": round(ff_ms, 4),
+                         "timed": ("HIP event pairs around the layer's forward call inside 4 training steps (16 calls: preparation "
+                                   "launch + the kernel), i.e. over the timed region's own launches" if ff_in_step
+                                   else "stand-alone loop of 10 launches"),
+                         "ms_per_launch_back_to_back_loop": round(ff["fwd_train_ms"], 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "note": "fp32 in / out / accumulate; hidden activations never leave the CU.  Neither roof is near: "
                                  "the kernel is bound by VALU issue (bias, dropout, GELU + GELU', f16 splitting, LayerNorm) -- "
                                  "SQ counters in profiles/"},
@@ -758,7 +797,11 @@ def main():
             "roofline_spectral": hbm("FSpectralConv2d.forward_fourier: k_mix_prep + k_dft_analysis_rr_h2 (both axes, the field read "
                                      "from HBM once, no cross-wave sums) + k_mix_h2 (mode mix of both axes, writes the synthesis "
                                      "operands) + k_dft_synthesis4_h2 (field written once, whole 128-byte lines)",
-                                     s_bytes, s_ms, traffic=spec_traffic,
+                                     s_bytes, spec_in_step if spec_in_step else s_ms, traffic=spec_traffic,
+                                     timed="HIP event pairs around the layer's forward call inside 4 training steps (16 calls): the "
+                                     "four launches at the clock the step runs at" if spec_in_step else "stand-alone loop",
+                                     ms_per_launch_back_to_back_loop=round(s_ms, 4),
+                                     frac_back_to_back_loop=round(s_bytes / (s_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                      traffic_over_algorithmic=(round(spec_traffic / s_bytes, 3) if spec_traffic else None),
                                      backward_ms=round(s_bwd_ms, 4), backward_frac=round(2 * s_bytes / (s_bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                      note="HBM traffic of the four launches (PMC, profiles/): field 1x in + 1x out, spectra "
