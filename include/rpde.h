@@ -358,11 +358,15 @@ int rpde_rel_l2_bwd(const float* x, const float* y, const float* stats,
 int rpde_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
                     float one_minus_lr_wd, float one_minus_b1, float b2, float one_minus_b2,
                     float step_size, float bc2_sqrt, float eps, void* stream);
-/* the same with the step counter on the device (step_dev[0..2]: t, lr/(1-b1^t), sqrt(1-b2^t); t is incremented
- * by the call): nothing step-dependent crosses the host, so the step can be captured in a hipGraph */
+/* the same with the step state on the device (step_dev: 8 floats -- [0] t, incremented by the call, [1] lr/(1-b1^t),
+ * [2] sqrt(1-b2^t), [3] lr, [4] weight decay, [5] 1 - lr*wd): nothing step-dependent crosses the host, so the step can be
+ * captured in a hipGraph.  Called eagerly it stores its lr / weight_decay arguments in step_dev first; while its stream
+ * is being captured it does not, and every replay runs with what rpde_adamw_set_hyper_dev put there -- a captured step
+ * follows a learning-rate schedule (main_1d.py:145-151, main_2d.py:174-180) without being captured again. */
 int rpde_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
                         float lr, float b1, float b2, float eps, float weight_decay,
                         float* step_dev, void* stream);
+int rpde_adamw_set_hyper_dev(float* step_dev, float lr, float weight_decay, void* stream);
 /* the update of rpde_adamw_step_dev without advancing the counter (a second buffer of the same optimizer step) */
 int rpde_adamw_apply_dev(float* p, const float* g, float* m, float* v, int64_t n,
                          float lr, float b1, float b2, float eps, float weight_decay,

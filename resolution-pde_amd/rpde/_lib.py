@@ -134,6 +134,7 @@ _SIGNATURES = {
     "rpde_rel_l2_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
     "rpde_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
     "rpde_adamw_step_dev": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),
+    "rpde_adamw_set_hyper_dev": (_I, [_P, _F, _F, _P]),
     "rpde_adamw_apply_dev": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P]),
 }
 

@@ -96,11 +96,14 @@ def run(dims: int, argv=None):
     lr = float(args.training.learning_rate)
     # torch.optim.AdamW's update rule and state_dict format, one kernel per step (rpde/optim.py)
     from rpde.optim import FlatAdamW
+    # training.graph=true (or RPDE_TRAIN_GRAPH=1): train() replays each batch shape's step as one hipGraph -- the optimizer's
+    # step state (count, learning rate, weight decay) then lives on the device
+    use_graph = bool(args.training.get("graph", False)) or os.environ.get("RPDE_TRAIN_GRAPH") == "1"
     if dims == 2:     # reference main_2d.py:173-174
-        optimizer = FlatAdamW(model.parameters(), lr=lr)
+        optimizer = FlatAdamW(model.parameters(), lr=lr, capturable=use_graph)
         scheduler = optim.lr_scheduler.StepLR(optimizer, step_size=30, gamma=0.5)
     else:             # reference main_1d.py:144-145
-        optimizer = FlatAdamW(model.parameters(), lr=lr, weight_decay=1e-4)
+        optimizer = FlatAdamW(model.parameters(), lr=lr, weight_decay=1e-4, capturable=use_graph)
         scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=100, eta_min=1e-5)
 
     n_params = sum(p.numel() for p in model.parameters())
@@ -112,7 +115,7 @@ def run(dims: int, argv=None):
     t0 = time.time()
     loss_hist, val_hist = train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=y_normalizer,
                                 use_normalizer=bool(args.training.use_normalizer), epochs=int(args.training.epochs),
-                                device=device)
+                                device=device, graph=use_graph)
     torch.cuda.synchronize()
     test_l2 = evaluate(model, test_loader, normalization_type=normalization_type, min_data=min_data, max_data=max_data,
                        min_model=min_model, max_model=max_model, y_normalizer=y_normalizer, device=device)

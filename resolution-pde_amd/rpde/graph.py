@@ -42,7 +42,17 @@ class GraphedTrainStep:
 
     x / y of later calls must have the example's shape and dtype (one graph per shape; build one instance per
     resolution for multi-resolution training).  `after_backward` (e.g. FlatGradBucket.all_reduce_mean) runs
-    inside the captured region between backward and the optimizer step."""
+    inside the captured region between backward and the optimizer step.
+
+    warmup = 0: the caller has already run eager steps of this very shape (plans, allocator pools and optimizer state
+    exist) -- the construction then applies NO optimizer step of its own, which is what a training loop needs
+    (train/training.py: the first steps of a shape run eagerly, the graph is captured in between two real steps).
+    With warmup = 0 the caller must not keep a loss / output tensor of an earlier eager step alive across the
+    construction: its autograd graph pins the parameters' gradient accumulators to the stream it ran on, and the
+    captured backward would then synchronise with that stream -- an illegal dependency inside a capture.
+    A learning-rate schedule: with rpde.optim.FlatAdamW(capturable=True) the values live on the device and are
+    refreshed before a replay when a scheduler has moved them; other optimizers bake them into the graph, and the
+    replay is refused once they change."""
 
     def __init__(self, model, loss_fn, optimizer, x: torch.Tensor, y: torch.Tensor, warmup: int = 3,
                  after_backward: Optional[Callable[[], None]] = None):
@@ -60,7 +70,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):      # creates DFT plans, sizes the allocator pools, primes optimizer state
+            for _ in range(max(0, warmup)):      # creates DFT plans, sizes the allocator pools, primes optimizer state
                 self._eager()
         torch.cuda.current_stream(x.device).wait_stream(side)
         torch.cuda.synchronize(x.device)
@@ -87,6 +97,9 @@ class GraphedTrainStep:
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         if x.shape != self.x.shape or y.shape != self.y.shape:
             raise ValueError(f"GraphedTrainStep was captured for {tuple(self.x.shape)} / {tuple(self.y.shape)}")
+        if self._hyper() != self._captured_hyper and hasattr(self.optimizer, "sync_hyper_to_device"):
+            self.optimizer.sync_hyper_to_device()          # device-side lr / weight decay: the graph reads them
+            self._captured_hyper = self._hyper()
         if self._hyper() != self._captured_hyper:
             raise RuntimeError(f"GraphedTrainStep: lr / weight_decay changed after capture ({self._captured_hyper} -> "
                                f"{self._hyper()}); the graph would keep training at the captured values -- build a new "

@@ -15,9 +15,9 @@ no moment update, no weight decay, its step count stands still.
 
 ``capturable=True`` keeps the step counter on the device (``rpde_adamw_step_dev``), which lets
 ``rpde.graph.GraphedTrainStep`` capture the step; it requires every parameter to take part in every step.
-Limit: ``lr`` and ``weight_decay`` reach the kernel as launch arguments, so a captured graph replays the values it
-was captured with -- ``GraphedTrainStep`` refuses to replay once a scheduler has changed them (re-capture per
-learning-rate plateau, or step eagerly).
+``lr`` and ``weight_decay`` live in that device state too: an eager ``step()`` stores the group's current values there, a
+captured one reads them, and ``GraphedTrainStep`` calls ``sync_hyper_to_device()`` before a replay once a scheduler has
+moved them -- a captured step follows the schedule without being captured again.
 """
 from __future__ import annotations
 
@@ -55,7 +55,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._offsets: List[int] = list(self.bucket.offsets)
         self._sizes: List[int] = [p.numel() * (2 if p.is_complex() else 1) for p in group_params]
         self._steps: List[int] = [0] * len(group_params)
-        self._step_dev = torch.zeros(4, dtype=torch.float32, device=dev) if capturable else None
+        self._step_dev = torch.zeros(8, dtype=torch.float32, device=dev) if capturable else None
         for i, (p, gview) in enumerate(zip(group_params, self.bucket._views)):
             r = 1 if p.is_complex() else 0
             off, size = self._offsets[i] - bounds[r][0], self._sizes[i]
@@ -142,6 +142,15 @@ class FlatAdamW(torch.optim.Optimizer):
                 self._steps[i] = t
             k = j + 1
         return loss
+
+    def sync_hyper_to_device(self) -> None:
+        """capturable only: put the group's current lr / weight_decay where captured steps read them (rpde.graph calls
+        this before a replay when a scheduler has moved them)"""
+        if self._step_dev is None:
+            raise RuntimeError("FlatAdamW.sync_hyper_to_device: build the optimizer with capturable=True")
+        g = self.param_groups[0]
+        check(load().rpde_adamw_set_hyper_dev(self._step_dev.data_ptr(), float(g["lr"]), float(g["weight_decay"]), stream_ptr()),
+              "adamw_set_hyper_dev")
 
     # ---- torch.optim.AdamW-compatible checkpoints ---------------------------------------------------------------
     def state_dict(self):

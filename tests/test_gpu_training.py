@@ -241,6 +241,41 @@ def test_graphed_train_step_matches_eager(gpu_device):
                          torch.randn(2, 1, 64, device=gpu_device), torch.randn(2, 1, 64, device=gpu_device))
 
 
+def test_train_loop_with_graph_follows_the_eager_loop_and_the_scheduler(gpu_device):
+    """train(..., graph=True) (reference loop: train/training.py:19-88): GRAPH_AFTER eager steps per batch shape, then one
+    hipGraph replay per step.  Same losses and weights as the eager loop over three epochs in which a StepLR halves the
+    learning rate every epoch (FlatAdamW keeps lr / weight decay on the device: no new capture), with two batch shapes
+    (a ragged last batch) and a validation pass between the epochs."""
+    import copy
+    from models.fno import FNO1d
+    from rpde.optim import FlatAdamW
+    from train.training import train
+    torch.manual_seed(11)
+    m_e = FNO1d(1, 1, modes=8, width=16).to(gpu_device)
+    m_g = copy.deepcopy(m_e)
+    data = [(torch.randn(1, 128), torch.randn(1, 128)) for _ in range(22)]        # batches of 4: five full + one of 2
+    loader = lambda: torch.utils.data.DataLoader(data, batch_size=4, shuffle=False)   # noqa: E731
+    hist = []
+    for m, graph in ((m_e, False), (m_g, True)):
+        opt = FlatAdamW(m.parameters(), lr=2e-3, weight_decay=1e-2, capturable=graph)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+        hist.append(train(m, loader(), loader(), opt, sched, epochs=3, device=gpu_device, graph=graph))
+        assert abs(opt.param_groups[0]["lr"] - 2e-3 * 0.125) < 1e-12
+    (tl_e, vl_e), (tl_g, vl_g) = hist
+    for a, b in zip(tl_e + vl_e, tl_g + vl_g):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), (tl_e, tl_g, vl_e, vl_g)
+    for pe, pg in zip(m_e.parameters(), m_g.parameters()):
+        a, b = torch.view_as_real(pe) if pe.is_complex() else pe, torch.view_as_real(pg) if pg.is_complex() else pg
+        assert float((a - b).norm() / (a.norm() + 1e-30)) < 2e-6
+    # had the replays kept the captured learning rate, the third epoch would have stepped 4x too far: make sure this
+    # test can tell (one more eager epoch at the wrong rate moves the weights measurably)
+    m_w = copy.deepcopy(m_e)
+    opt = FlatAdamW(m_w.parameters(), lr=2e-3, weight_decay=1e-2)
+    train(m_w, loader(), loader(), opt, None, epochs=3, device=gpu_device, graph=False)
+    pe, pw = next(m_e.parameters()), next(m_w.parameters())
+    assert float((pe - pw).norm() / pe.norm()) > 1e-4
+
+
 @pytest.mark.parametrize("dim,factor", [(64, 4), (32, 2)])          # the fused kernels / the per-GEMM path
 def test_dropout_device_epoch_changes_masks_and_keeps_backward_in_step(gpu_device, dim, factor):
     """rpde_ff_params.seed_epoch: the device counter every dropout kernel mixes into its seed (what lets a captured
@@ -611,20 +646,44 @@ def test_flat_adamw_loads_a_torch_state_dict_with_a_never_stepped_parameter(gpu_
     assert torch.allclose(a, a2, rtol=1e-6, atol=1e-7) and torch.allclose(b, b2, rtol=1e-6, atol=1e-7)
 
 
-def test_graphed_step_refuses_a_changed_learning_rate(gpu_device):
+def test_graphed_step_follows_or_refuses_a_changed_learning_rate(gpu_device):
+    """FlatAdamW(capturable=True) keeps lr / weight decay on the device (rpde_adamw_set_hyper_dev): a replay after a
+    scheduler step trains at the new rate -- the same weights as eager steps at that rate.  An optimizer that bakes the
+    rate into the captured launches is refused instead of silently training at the old one."""
+    import copy
     from models.fno import FNO1d
     from rpde.graph import GraphedTrainStep
     from rpde.optim import FlatAdamW
     from utils.loss import RelativeL2Loss
     torch.manual_seed(0)
     m = FNO1d(1, 1, modes=8, width=16).to(gpu_device).train()
-    opt = FlatAdamW(m.parameters(), lr=1e-3, capturable=True)
+    m_ref = copy.deepcopy(m)
+    loss_fn = RelativeL2Loss()
+    opt = FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-2, capturable=True)
     x, y = torch.randn(4, 1, 128, device=gpu_device), torch.randn(4, 1, 128, device=gpu_device)
-    step = GraphedTrainStep(m, RelativeL2Loss(), opt, x, y)
+    step = GraphedTrainStep(m, loss_fn, opt, x, y, warmup=2)
     step(x, y)
     opt.param_groups[0]["lr"] = 5e-4                                   # what a scheduler does
+    opt.param_groups[0]["weight_decay"] = 3e-2
+    step(x, y)
+    step(x, y)
+    ref = FlatAdamW(m_ref.parameters(), lr=1e-3, weight_decay=1e-2)
+    for i in range(5):                                                 # 2 warm-up + 1 at the old rate, 2 at the new one
+        if i == 3:
+            ref.param_groups[0]["lr"], ref.param_groups[0]["weight_decay"] = 5e-4, 3e-2
+        ref.zero_grad()
+        loss_fn(m_ref(x), y).backward()
+        ref.step()
+    for pg, pe in zip(m.parameters(), m_ref.parameters()):
+        a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (pg, pe))
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-6
+    m2 = FNO1d(1, 1, modes=8, width=16).to(gpu_device).train()
+    topt = torch.optim.AdamW(m2.parameters(), lr=1e-3, capturable=True)
+    step2 = GraphedTrainStep(m2, loss_fn, topt, x, y)
+    step2(x, y)
+    topt.param_groups[0]["lr"] = 5e-4
     with pytest.raises(RuntimeError, match="changed after capture"):
-        step(x, y)
+        step2(x, y)
 
 
 def test_rollout_fused_renormalisation_equals_decode_then_encode(gpu_device):
