@@ -50,3 +50,22 @@ def test_spawn_ranks_helper_propagates_and_terminates(tmp_path):
     assert spawn_ranks(str(script), [], 2) == 5
     env = rank_env(1, 4, 1234, base={})
     assert env["RANK"] == "1" and env["WORLD_SIZE"] == "4" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_host_thread_pool_is_sized_by_the_usable_cores(monkeypatch):
+    """rpde.launch.host_cores / limit_host_threads: the affinity mask capped by the cgroup quota and RPDE_CPU_THREADS,
+    shared between the ranks of a node; the pool is only ever made smaller"""
+    import torch
+    from rpde import launch
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setenv("RPDE_CPU_THREADS", "6")
+        n = launch.host_cores()
+        assert 1 <= n <= 6
+        torch.set_num_threads(max(before, 8))
+        got = launch.limit_host_threads(world=4)
+        assert got == max(1, n // 4) and torch.get_num_threads() == got
+        torch.set_num_threads(1)
+        assert launch.limit_host_threads(world=1) == 1          # never raised
+    finally:
+        torch.set_num_threads(before)
