@@ -57,3 +57,32 @@ def test_fno2d_and_fno1d_odd(gpu_device):
     import torch.nn.functional as F
     m1 = FNO1d(3, 1, 5, 7, activation=F.gelu, n_blocks=2).to(gpu_device).train()
     _compare(m1, lambda p, xx: R.fno1d_forward(p, xx, 2, "gelu"), torch.randn(2, 3, 19))
+
+
+@pytest.mark.parametrize("dim,factor,n_layers,P", [(32, 2, 1, 700), (48, 4, 4, 2500), (32, 2, 5, 1500), (16, 3, 6, 1200),
+                                                   (128, 4, 3, 8192)])
+def test_feedforward_depths_around_the_one_launch_limits(gpu_device, dim, factor, n_layers, P):
+    """The GEMM-path FeedForward splits the weight images of up to four layers in one launch and folds up to twelve slab
+    sets in one launch (csrc/feedforward.hip: SplitJobs, FoldJobs); deeper stacks fall back to per-layer launches for
+    what does not fit.  Forward and every gradient against the float64 restatement of models/custom_layer.py:49-68 for
+    1 .. 6 layers (and the 128-wide yaml shape of FFNO1D)."""
+    from models.custom_layer import FeedForward
+    from oracle import reference_path as R
+    torch.manual_seed(n_layers * 100 + dim)
+    ff = FeedForward(dim, factor, n_layers=n_layers, layer_norm=True, dropout=0.0).to(gpu_device).train()
+    x = torch.randn(P, dim, device=gpu_device, requires_grad=True)
+    probe = torch.randn(P, dim, device=gpu_device)
+    out = ff(x)
+    (out * probe).sum().backward()
+    sd = {k: v.detach().double().cpu().requires_grad_() for k, v in ff.state_dict().items()}
+    xd = x.detach().double().cpu().requires_grad_()
+    ref = R.feedforward(xd, sd, "", n_layers, True)
+    (ref * probe.double().cpu()).sum().backward()
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm().clamp_min(1e-30))
+
+    assert rel(out.detach(), ref.detach()) < 5e-6
+    assert rel(x.grad, xd.grad) < 2e-5
+    for k, p in ff.named_parameters():
+        assert rel(p.grad, sd[k].grad) < 2e-5, k
