@@ -62,6 +62,8 @@ def train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=No
     if graph is None:
         graph = os.environ.get("RPDE_TRAIN_GRAPH") == "1"
     graph = bool(graph) and hasattr(optimizer, "sync_hyper_to_device") and getattr(optimizer, "_step_dev", None) is not None
+    if graph and _dist_on() and dist.get_backend() != "nccl":
+        graph = False            # only RCCL's all-reduce is a stream operation a capture can record (gloo runs on the host)
     decode = use_normalizer and y_normalizer is not None
 
     def step_loss(pred_y, batch_y):
