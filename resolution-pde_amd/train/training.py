@@ -65,6 +65,16 @@ def train(model, train_loader, val_loader, optimizer, scheduler, y_normalizer=No
     if graph and _dist_on() and dist.get_backend() != "nccl":
         graph = False            # only RCCL's all-reduce is a stream operation a capture can record (gloo runs on the host)
     decode = use_normalizer and y_normalizer is not None
+    if decode:
+        # the reference's normalisers keep their statistics where they were computed and move them in every decode() call
+        # (models/custom_layer.py:31): a shallow copy with device-resident tensors makes those moves no-ops -- two
+        # host-to-device copies less per step, and nothing a hipGraph capture would have to refuse
+        import copy
+        resident = copy.copy(y_normalizer)
+        for k, v in vars(y_normalizer).items():
+            if torch.is_tensor(v):
+                setattr(resident, k, v.to(device))
+        y_normalizer = resident
 
     def step_loss(pred_y, batch_y):
         if decode:
