@@ -89,9 +89,14 @@ __device__ __forceinline__ float lane_xor32(float v) {
 
 // three-term product of split operands, small terms first
 __device__ __forceinline__ f32x4v h2_mfma32(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x4v c) {
+#ifdef RPDE_EXP_H2_1TERM      // TIMING EXPERIMENT ONLY (wrong to 2^-11): what the two correction terms cost in time / energy
+  (void)al; (void)bl;
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+#else
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+#endif
 }
 // (There is deliberately no 16-deep variant on v_mfma_f32_16x16x16_f16.  Round 2 saw wrong accumulators when the fused
 //  synthesis kernel closed a 32-deep chain with a 16-deep tail; round 4 reduced it to two instructions
