@@ -79,7 +79,7 @@ static int linear_wgrad_impl(const float* x, const float* gy, float* gw, float* 
     if (out_f <= 4 && thin_linear_ok(out_f, in_f) && al16(x)) return thin_outer(gy, x, gw, 0, nullptr, gb, P, out_f, in_f, ws_slabs, st);
   }
   if (gw && wgrad_h2_ok(P, out_f, in_f)) {
-    RPDE_TRY(wgrad_h2(gy, x, gw, P, in_f, out_f, act_x, ws_slabs, st));
+    RPDE_TRY(wgrad_h2(gy, x, gw, P, in_f, out_f, act_x, ws_slabs, st, defer));
   } else if (gw) {
     const int S = wgrad_split(P, out_f, in_f);
     rpde_gemm_desc d = gemm_desc();
@@ -275,7 +275,6 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
   float* small = ar.take(colsum_ws_floats(P, hid));
   float* tailws = ar.take(ff_tail_bwd_ws_floats(P, p->dim));
   if (!ar.ok()) { set_error("feedforward_bwd: workspace too small (%zu bytes given)", ws_bytes); return RPDE_ERR_WORKSPACE; }
-  float* slabs = slabs_l[0];
   void* wt = wt_l[0];
 
   if (ff3_fused_ok(p, P) && hs && hs[0] && hs[1]) {
@@ -295,10 +294,13 @@ int rpde_feedforward_bwd(const rpde_ff_params* p, const float* x, const float* c
     const bool both = grad_x && grad_weights && wgrad_h2_dgrad_ok(P, hid, p->dim);
     if (grad_x && !both) RPDE_TRY(linear_dgrad_impl(buf1, p->weights[0], grad_x, P, p->dim, hid, nullptr, nullptr, st, wt));
     if (grad_weights) {
-      RPDE_TRY(linear_wgrad_impl(hs[1], dz3, grad_weights[2], nullptr, P, hid, p->dim, slabs, small, st, act_h));
-      RPDE_TRY(linear_wgrad_impl(hs[0], buf0, grad_weights[1], nullptr, P, hid, hid, slabs, small, st, act_h));
-      if (both) RPDE_TRY(wgrad_h2_dgrad(buf1, x, p->weights[0], grad_weights[0], grad_x, P, p->dim, hid, slabs, st));
-      else RPDE_TRY(linear_wgrad_impl(x, buf1, grad_weights[0], nullptr, P, p->dim, hid, slabs, small, st));
+      // each weight gradient in its own slab region, the three folds in one launch
+      FoldJobs folds;
+      RPDE_TRY(linear_wgrad_impl(hs[1], dz3, grad_weights[2], nullptr, P, hid, p->dim, slabs_l[2], small, st, act_h, &folds));
+      RPDE_TRY(linear_wgrad_impl(hs[0], buf0, grad_weights[1], nullptr, P, hid, hid, slabs_l[1], small, st, act_h, &folds));
+      if (both) RPDE_TRY(wgrad_h2_dgrad(buf1, x, p->weights[0], grad_weights[0], grad_x, P, p->dim, hid, slabs_l[0], st, &folds));
+      else RPDE_TRY(linear_wgrad_impl(x, buf1, grad_weights[0], nullptr, P, p->dim, hid, slabs_l[0], small, st, RPDE_ACT_IDENTITY, &folds));
+      RPDE_TRY(fold_jobs(folds, st));
     }
     {   // per-workgroup partial sums -> the five small gradients, one launch
       ReduceSegs sg;

@@ -328,7 +328,7 @@ static void wg_launch(const WgP& p, int mblocks, bool act, hipStream_t st) {
 bool wgrad_h2_dgrad_ok(long P, int out_f, int in_f) { return wgrad_h2_ok(P, out_f, in_f) && out_f == 256 && in_f == 64; }
 
 int wgrad_h2_dgrad(const float* gy, const float* h, const float* w, float* gw, float* gx, long P, int in_f, int out_f,
-                   float* slabs, hipStream_t st) {
+                   float* slabs, hipStream_t st, FoldJobs* defer) {
   RPDE_CHECK_ARG(wgrad_h2_dgrad_ok(P, out_f, in_f) && slabs && w && gx, "wgrad_h2_dgrad: unsupported shape");
   WgP p;
   p.a = gy; p.b = h; p.slabs = slabs; p.npts = P; p.steps = (P + 31) / 32; p.M = out_f; p.N = in_f; p.nchunk = WG_BLOCKS;
@@ -336,10 +336,12 @@ int wgrad_h2_dgrad(const float* gy, const float* h, const float* w, float* gw, f
   p.w = w; p.gx = gx;
   hipLaunchKernelGGL((k_wgrad_h2<4, 1, 4, 2, 4, 2, false, true>), dim3(p.nchunk, 1), dim3(64 * WG_WAVES), 0, st, p);
   RPDE_LAUNCH_CHECK();
+  if (defer && defer->add(slabs, gw, out_f * in_f, p.nchunk, (long)out_f * in_f)) return RPDE_OK;
   return reduce_slabs(slabs, gw, (long)out_f * in_f, p.nchunk, (long)out_f * in_f, 1.f, 0, st);
 }
 
-int wgrad_h2(const float* gy, const float* h, float* gw, long P, int in_f, int out_f, int act_b, float* slabs, hipStream_t st) {
+int wgrad_h2(const float* gy, const float* h, float* gw, long P, int in_f, int out_f, int act_b, float* slabs, hipStream_t st,
+             FoldJobs* defer) {
   RPDE_CHECK_ARG(wgrad_h2_ok(P, out_f, in_f) && slabs, "wgrad_h2: unsupported shape");
   RPDE_CHECK_ARG(act_b == RPDE_ACT_IDENTITY || act_b == RPDE_ACT_GELU, "wgrad_h2: activation %d", act_b);
   WgP p;
@@ -351,6 +353,7 @@ int wgrad_h2(const float* gy, const float* h, float* gw, long P, int in_f, int o
   else if (out_f == 256) wg_launch<4, 1, 4, 2, 4, 2>(p, 1, act, st);
   else wg_launch<1, 4, 1, 8, 4, 2>(p, 1, act, st);
   RPDE_LAUNCH_CHECK();
+  if (defer && defer->add(slabs, gw, out_f * in_f, p.nchunk, (long)out_f * in_f)) return RPDE_OK;
   return reduce_slabs(slabs, gw, (long)out_f * in_f, p.nchunk, (long)out_f * in_f, 1.f, 0, st);
 }
 
